@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Mint golden vectors by importing the reference (CPU, this container only).
+
+Run from the repo root:   python tests/golden/make_golden.py
+
+The reference lives at /root/reference (read-only) and never travels to the GPU
+box; only the *outputs* written here (small ``.npz`` files of inputs and expected
+outputs) are committed.  ``captum`` / ``torchsummary`` are absent from this image
+and are replaced by empty stub modules (only the ``'uniform'`` importance path,
+which never touches captum, is exercised) -- see SURVEY.md section 8(c).
+
+``fusion_algorithms/otfusion.py`` cannot be imported (``import ot``: POT is not
+installed), so there is no OTFusion golden: OTFusion parity is *unpinned* at the
+``ot.emd`` boundary.
+
+What is recorded, per fixture (keys are flat strings inside one npz):
+  sd{k}.<param>               state_dict of input model k (reference class, seeded init or real ckpt)
+  X                           fusion samples
+  gr.cost{l}, gr.col{l}       GitRebasin cost matrix + LSA column indices per layer
+  gr.fused.<param>            GitRebasin fused weights
+  hf.w0_{l}, hf.w1_{l}        pinv(X) @ acts per layer (LS refit)
+  hf.cost{l}, hf.col{l}       HF cost matrix + LSA column indices
+  hf.fused.<param>
+  kf{M}.assign{l}             KF best assignment per layer (M models), under np.random.seed(SEED)
+  kf{M}.fused.<param>
+  alf.T.{norm}{init2}, alf.assign.{norm}{init2}   ALFusion._k_means_v2 at level 0
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+SEED = 1234
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    for name in ['captum', 'captum.attr', 'torchsummary']:
+        sys.modules[name] = types.ModuleType(name)
+    for c in ['LayerConductance', 'LayerDeepLift', 'LayerFeatureAblation']:
+        setattr(sys.modules['captum.attr'], c, type(c, (), {}))
+    sys.modules['torchsummary'].summary = lambda *a, **k: None
+
+
+_import_reference()
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from fusion_algorithms import alf as ref_alf  # noqa: E402
+from fusion_algorithms import git_rebasin as ref_gr  # noqa: E402
+from fusion_algorithms import hf_kf as ref_hf  # noqa: E402
+from models.mlp import MLPNet  # noqa: E402
+from models.vgg import VGG  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def sd_to(out, prefix, model):
+    for k, v in model.state_dict().items():
+        out[f'{prefix}.{k}'] = v.detach().cpu().numpy()
+
+
+class Recorder:
+    """Wrap module-level callables of the reference to log their inputs/outputs."""
+
+    def __init__(self):
+        self.lsa = []          # (cost, col)
+        self.hf_cost_args = []  # (w0, w1)
+        self.centroid_calls = []  # assignment of every _calculate_centroids call
+
+    def wrap_lsa(self, mod):
+        orig = mod.linear_sum_assignment
+
+        def f(cost):
+            r, c = orig(cost)
+            self.lsa.append((np.array(cost, dtype=np.float32), np.array(c, dtype=np.int64)))
+            return r, c
+        mod.linear_sum_assignment = f
+        return orig
+
+    def wrap_hf_cost(self):
+        orig = ref_hf.LSFusion._get_cost_matrix_vectorized_chunked
+
+        def f(X, acts0, acts1, w0, w1, s0, s1, *a, **k):
+            self.hf_cost_args.append((w0.numpy().copy(), w1.numpy().copy()))
+            return orig(X, acts0, acts1, w0, w1, s0, s1, *a, **k)
+        ref_hf.LSFusion._get_cost_matrix_vectorized_chunked = staticmethod(f)
+        return orig
+
+    def wrap_centroids(self):
+        orig = ref_hf.LSFusion._calculate_centroids
+
+        def f(output_size, assignment, X, w, s):
+            self.centroid_calls.append(np.array(torch.as_tensor(assignment).cpu().numpy(), dtype=np.int64))
+            return orig(output_size, assignment, X, w, s)
+        ref_hf.LSFusion._calculate_centroids = staticmethod(f)
+        return orig
+
+
+def run_gr(out, models, X):
+    rec = Recorder()
+    orig = rec.wrap_lsa(ref_gr)
+    fused = quiet(ref_gr.GitRebasin(models[0], models[1]).fuse, X, None, 'uniform')
+    ref_gr.linear_sum_assignment = orig
+    for l, (cost, col) in enumerate(rec.lsa):
+        out[f'gr.cost{l}'] = cost
+        out[f'gr.col{l}'] = col
+    sd_to(out, 'gr.fused', fused)
+
+
+def run_hf(out, models, X, norm_acts=False):
+    rec = Recorder()
+    o1 = rec.wrap_lsa(ref_hf)
+    o2 = rec.wrap_hf_cost()
+    fused = quiet(ref_hf.LSFusion(models[:2]).fuse, X, None, fusion_method='hungarian',
+                  neuron_importance_method='uniform', norm_acts=norm_acts)
+    ref_hf.linear_sum_assignment = o1
+    ref_hf.LSFusion._get_cost_matrix_vectorized_chunked = staticmethod(o2)
+    tag = 'hfn' if norm_acts else 'hf'
+    for l, (cost, col) in enumerate(rec.lsa):
+        out[f'{tag}.cost{l}'] = cost
+        out[f'{tag}.col{l}'] = col
+    for l, (w0, w1) in enumerate(rec.hf_cost_args):
+        out[f'{tag}.w0_{l}'] = w0
+        out[f'{tag}.w1_{l}'] = w1
+    sd_to(out, f'{tag}.fused', fused)
+
+
+def run_kf(out, models, X):
+    M = len(models)
+    rec = Recorder()
+    o = rec.wrap_centroids()
+    # mark layer boundaries: the last _calculate_centroids call inside one
+    # _fuse_layer_k_means call receives best_assignment (hf_kf.py:494)
+    ends = []
+    orig_layer = ref_hf.LSFusion._fuse_layer_k_means
+
+    def layer_wrapper(self, *a, **k):
+        r = orig_layer(self, *a, **k)
+        ends.append(len(rec.centroid_calls))
+        return r
+    ref_hf.LSFusion._fuse_layer_k_means = layer_wrapper
+    np.random.seed(SEED)
+    fused = quiet(ref_hf.LSFusion(models).fuse, X, None, fusion_method='k_means',
+                  neuron_importance_method='uniform')
+    ref_hf.LSFusion._calculate_centroids = staticmethod(o)
+    ref_hf.LSFusion._fuse_layer_k_means = orig_layer
+    prev = 0
+    ncalls = []
+    for l, e in enumerate(ends):
+        out[f'kf{M}.assign{l}'] = rec.centroid_calls[e - 1]
+        ncalls.append(e - prev)
+        prev = e
+    out[f'kf{M}.ncalls'] = np.array(ncalls, dtype=np.int64)
+    sd_to(out, f'kf{M}.fused', fused)
+
+
+def run_alf_kmeans(out, models, X, level_idx=0):
+    alf = ref_alf.ALFusion(models)
+    nlev = len(models[0].get_ordered_trainable_named_levels)
+    alf.ni_scores = [{l: torch.ones(models[k].get_ordered_trainable_named_levels[l].output_width)
+                      for l in range(nlev)} for k in range(len(models))]
+    width = models[0].get_ordered_trainable_named_levels[level_idx].output_width
+    for norm in (False, True):
+        for init2 in (False, True):
+            cfg = ref_alf.ALFusionConfig(
+                X=X, y=None, optimizer_per_level=['adam'] * nlev, lr_per_level=[1e-3] * nlev,
+                weight_decay_per_level=[0.0] * nlev, epochs_per_level=[1] * nlev,
+                normalize_acts_for_kmeans=norm, init_kmeans_with_2nd_acts=init2, verbose=False)
+            level_X = X
+            with torch.no_grad():
+                T, assign = quiet(alf._k_means_v2, level_idx, width, cfg, level_X)
+            tag = f'{int(norm)}{int(init2)}'
+            out[f'alf.T.{tag}'] = T.numpy()
+            out[f'alf.assign.{tag}'] = assign.numpy().astype(np.int64)
+
+
+def run_alf_fuse(out, models, X, epochs=2):
+    """End-to-end ALFusion.fuse with a short Adam fit (torch RNG seeded)."""
+    nlev = len(models[0].get_ordered_trainable_named_levels)
+    cfg = ref_alf.ALFusionConfig(
+        X=X, y=None, optimizer_per_level=['adam'] * nlev, lr_per_level=[1e-3] * nlev,
+        weight_decay_per_level=[0.0] * nlev, epochs_per_level=[epochs] * nlev,
+        normalize_acts_for_kmeans=True, init_kmeans_with_2nd_acts=False, verbose=False)
+    torch.manual_seed(SEED)
+    alf = ref_alf.ALFusion(models)
+    import tqdm  # noqa: F401
+    with contextlib.redirect_stderr(io.StringIO()):
+        fused = quiet(alf.fuse, cfg)
+    sd_to(out, 'alf.fused', fused)
+    out['alf.weight_change'] = np.array(alf.weight_change_per_level, dtype=np.float64)
+
+
+def meta(out):
+    out['meta.versions'] = np.array([f'torch={torch.__version__}', f'numpy={np.__version__}',
+                                     f'scipy={scipy.__version__}'])
+    out['meta.seed'] = np.array([SEED])
+
+
+def fixture_mlp_small():
+    out = {}
+    models = []
+    for k in range(4):
+        torch.manual_seed(100 + k)
+        models.append(MLPNet(20, 32, 10, use_bias=True, use_activations=False).eval())
+    torch.manual_seed(0)
+    X = torch.randn(48, 1, 4, 5)
+    out['X'] = X.numpy()
+    for k, m in enumerate(models):
+        sd_to(out, f'sd{k}', m)
+    run_gr(out, models, X)
+    run_hf(out, models, X)
+    run_hf(out, models, X, norm_acts=True)
+    run_kf(out, models[:2], X)
+    run_kf(out, models, X)
+    run_alf_kmeans(out, models[:2], X)
+    run_alf_fuse(out, [m.copy_model() for m in models[:2]], X)
+    meta(out)
+    np.savez_compressed(os.path.join(OUT, 'mlp_small.npz'), **out)
+    return out
+
+
+def fixture_mlp_wide():
+    """Over-determined MLP (m > d) with a wider hidden layer: exercises the m > d LS refit."""
+    out = {}
+    models = []
+    for k in range(3):
+        torch.manual_seed(200 + k)
+        models.append(MLPNet(24, 96, 10, use_bias=True, use_activations=False).eval())
+    torch.manual_seed(1)
+    X = torch.randn(256, 1, 4, 6)
+    out['X'] = X.numpy()
+    for k, m in enumerate(models):
+        sd_to(out, f'sd{k}', m)
+    run_gr(out, models, X)
+    run_hf(out, models, X)
+    run_kf(out, models, X)
+    run_alf_kmeans(out, models[:2], X)
+    meta(out)
+    np.savez_compressed(os.path.join(OUT, 'mlp_wide.npz'), **out)
+    return out
+
+
+def fixture_vgg_tiny():
+    out = {}
+    # a narrow configuration of the reference's own VGG class (widths are data, not code)
+    VGG.cfg['VGG_tiny'] = [8, 'M', 16, 'M', 16, 16, 'M', 32, 32, 'M', 32, 32, 'M']
+    models = []
+    for k in range(3):
+        torch.manual_seed(300 + k)
+        models.append(VGG('VGG_tiny', 10, (3, 32, 32), batch_norm=False, use_bias=True,
+                          use_activations=False).eval())
+    torch.manual_seed(2)
+    X = torch.randn(6, 3, 32, 32)
+    out['X'] = X.numpy()
+    out['cfg'] = np.array([str(c) for c in VGG.cfg['VGG_tiny']])
+    for k, m in enumerate(models):
+        sd_to(out, f'sd{k}', m)
+    run_gr(out, models, X)
+    run_hf(out, models, X)
+    run_kf(out, models, X)
+    run_alf_kmeans(out, models[:2], X, level_idx=2)
+    meta(out)
+    np.savez_compressed(os.path.join(OUT, 'vgg_tiny.npz'), **out)
+    return out
+
+
+def fixture_mlp_real():
+    """The reference's own MNIST split-by-2 checkpoints (real trained weights), synthetic X."""
+    out = {}
+    torch.serialization.add_safe_globals([MLPNet, nn.Linear, nn.Sequential, nn.Flatten, nn.ReLU, set])
+    base = os.path.join(REF, 'example-base-models/non-iid/MLPs/MNIST/split-by-2/seed1')
+    models = [torch.load(os.path.join(base, f'model_{i}.pt'), weights_only=True, map_location='cpu').eval()
+              for i in range(2)]
+    torch.manual_seed(3)
+    X = torch.randn(400, 1, 28, 28)
+    out['X'] = X.numpy().astype(np.float16)  # halves the fixture; tests up-cast the stored fp16 values
+    X = torch.from_numpy(out['X'].astype(np.float32))
+    for k, m in enumerate(models):
+        sd_to(out, f'sd{k}', m)
+    run_gr(out, models, X)
+    run_hf(out, models, X)
+    # keep the fixture small: drop the big LS solutions (785 x 256 each); cost + perm + fused stay
+    for key in list(out):
+        if key.startswith('hf.w'):
+            del out[key]
+    meta(out)
+    np.savez_compressed(os.path.join(OUT, 'mlp_real.npz'), **out)
+    return out
+
+
+if __name__ == '__main__':
+    for fx in (fixture_mlp_small, fixture_mlp_wide, fixture_vgg_tiny, fixture_mlp_real):
+        o = fx()
+        print(fx.__name__, len(o), 'arrays')
