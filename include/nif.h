@@ -1,0 +1,123 @@
+/*
+ * nif.h -- C ABI of libnif.so: the MI355X (gfx950) kernels under the per-level
+ * neuron matching-and-refit path of model fusion.
+ *
+ * The reference project (AndrewSpano/neuron-interpolation-model-fusion) is pure
+ * Python and has no FFI layer; each entry point below names the reference call
+ * site (path:line under the reference tree) whose arithmetic it replaces.  The
+ * reference-side binding a maintainer would add is the ctypes stub shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its comment says "host";
+ *   - the caller owns every buffer, including the workspace (query its size with
+ *     the matching *_workspace_bytes function); the library never allocates;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     no entry point synchronises the host unless its comment says so;
+ *   - return value: NIF_OK (0) or a negative NIF_ERR_* code; nothing throws;
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
+ */
+#ifndef NIF_H_
+#define NIF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIF_OK 0
+#define NIF_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum */
+#define NIF_ERR_WORKSPACE (-2)     /* workspace too small */
+#define NIF_ERR_UNSUPPORTED (-3)   /* size outside what the kernels cover */
+#define NIF_ERR_LAUNCH (-4)        /* hipGetLastError() != hipSuccess after a launch */
+#define NIF_ERR_NO_DEVICE (-5)
+
+/* element types of nif_xty inputs */
+#define NIF_F32 0
+#define NIF_F64 1
+
+/* nif_xty flags */
+#define NIF_RELU_A 1      /* clamp A's elements at 0 while loading (git_rebasin.py:97) */
+#define NIF_RELU_B 2      /* same for B (git_rebasin.py:98) */
+#define NIF_SYMMETRIC 4   /* B is A (same pointer, n1 == n0): only the upper tile triangle is computed */
+#define NIF_TRANS_A 8     /* A is stored as its transpose: n0 x m row-major (contraction over the contiguous axis) */
+#define NIF_TRANS_B 16    /* same for B */
+
+int nif_version(void);
+const char* nif_error_string(int code);
+/* number of HIP devices visible, or a negative error code (host call, no allocation) */
+int nif_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * nif_xty: G = A^T B summed over the m sample rows, plus the squared column
+ * norms na[i] = sum_r A[r][i]^2, nb[j] = sum_r B[r][j]^2.
+ *
+ * This is the one GEMM under every cost matrix of the path:
+ *   - Git Re-Basin cost            git_rebasin.py:60-78   (acts0^T acts1, ReLU on load)
+ *   - OTFusion ground metric       otfusion.py:135-150    (torch.cdist of activation columns)
+ *   - HF cost matrix               hf_kf.py:93-124        (via X^T X, X^T acts: see nif_cost_hf)
+ *   - KF / ALF k-means distances   hf_kf.py:429,440,455 ; alf.py:227,243,276 (Gram form)
+ *   - ALF target/input matching    alf.py:126-143
+ *   - LS refit normal equations    hf_kf.py:213,233-234,377,397 (X^T X and X^T acts, f64 accumulate)
+ *
+ * A is m x n0 (lda), B is m x n1 (ldb); with NIF_TRANS_* the operand is stored
+ * n x m.  in_dtype is the element type of A and B; acc selects the matrix-core
+ * path: NIF_F32 = v_mfma_f32_32x32x2_f32 (exact f32 fma chains per row block,
+ * row blocks summed in f64), NIF_F64 = v_mfma_f64_16x16x4_f64 (f32 inputs are
+ * widened exactly).  in_dtype NIF_F64 requires acc NIF_F64.
+ * G (n0 x n1, ldg), na (n0) and nb (n1) are f64; na / nb may be NULL.
+ * The row range is split over workgroups; partial tiles go through `ws`
+ * and are summed in a fixed order, so results are bitwise reproducible.
+ * ------------------------------------------------------------------------- */
+size_t nif_xty_workspace_bytes(int64_t m, int n0, int n1, int acc, int flags);
+int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, int n0, int n1,
+            int in_dtype, int acc, int flags, double* G, int64_t ldg, double* na, double* nb,
+            void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Cost-matrix epilogues: O(1) work per (i, j) on top of the Gram quantities.
+ * C is n0 x n1 f32 (ldc), the layout scipy.optimize.linear_sum_assignment /
+ * ot.emd receive in the reference.
+ * ------------------------------------------------------------------------- */
+
+/* C[i][j] = scale_ij * sqrt(max(na[i] + nb[j] - 2 G[i][j], 0)).
+ *  s0 == s1 == NULL: scale = 1          -> OTFusion ground metric, otfusion.py:150,182
+ *  otherwise scale = 2 s0[i] s1[j] / (s0[i] + s1[j]) -> Git Re-Basin cost, git_rebasin.py:70-77
+ *  (closed form of s0*||avg - a0|| + s1*||avg - a1||, avg the importance-weighted mean).
+ *  colscale (n1, may be NULL) multiplies column j afterwards -> alf.py:135-136 (dists * W). */
+int nif_cost_dist(const double* G, int64_t ldg, const double* na, const double* nb,
+                  const float* s0, const float* s1, const float* colscale, int n0, int n1,
+                  float* C, int64_t ldc, void* stream);
+
+/* HF cost, hf_kf.py:109-119 in closed form: with p = projected activations X w,
+ *   D = pp0[i] + pp1[j] - 2 G01[i][j]              (||p0_i - p1_j||^2)
+ *   a = s0[i] / (s0[i] + s1[j]),  b = 1 - a
+ *   C = s0[i] sqrt(b^2 D + r0[i]) + s1[j] sqrt(a^2 D + r1[j])
+ * G01 = P0^T P1 (n0 x n1), pp = squared norms of the projections, r = squared LS residuals. */
+int nif_cost_hf(const double* G01, int64_t ldg, const double* pp0, const double* pp1,
+                const double* r0, const double* r1, const float* s0, const float* s1,
+                int n0, int n1, float* C, int64_t ldc, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * nif_lap_solve_f32: min-cost perfect matching of an n x n f32 cost matrix;
+ * replaces scipy.optimize.linear_sum_assignment at hf_kf.py:251,
+ * git_rebasin.py:112, alf.py:138,383 (and ot.emd at otfusion.py:32,309 when both
+ * marginals are uniform and the problem is square: the exact plan is P/n).
+ * col4row[i] = column matched to row i (== scipy's col_ind, rows sorted).
+ * Exact (f64 duals, shortest augmenting paths after a parallel dual
+ * initialisation); equals scipy wherever the optimum is unique.
+ * row4col (n), u (n), v (n) are optional outputs (NULL to skip): the dual
+ * certificate u[i] + v[j] <= C[i][j] with equality on matched pairs.
+ * n <= NIF_LAP_MAX_N.  Costs must be finite.
+ * ------------------------------------------------------------------------- */
+#define NIF_LAP_MAX_N 8192
+size_t nif_lap_workspace_bytes(int n);
+int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int32_t* col4row, int32_t* row4col,
+                      double* u, double* v, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIF_H_ */

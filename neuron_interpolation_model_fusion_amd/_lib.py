@@ -1,0 +1,57 @@
+"""ctypes binding of libnif.so (the C ABI declared in include/nif.h).
+
+The library is built in-tree (``csrc/libnif.so``, see ``__graft_entry__.build``).
+There is no fallback: if the shared object is missing or a symbol is absent the
+import fails loudly, and every op raises on a non-zero status.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libnif.so')
+
+NIF_F32, NIF_F64 = 0, 1
+NIF_RELU_A, NIF_RELU_B, NIF_SYMMETRIC, NIF_TRANS_A, NIF_TRANS_B = 1, 2, 4, 8, 16
+NIF_LAP_MAX_N = 8192
+
+_c = ctypes
+_vp, _i32, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/nif.h one to one
+SIGNATURES = {
+    'nif_version': (_i32, []),
+    'nif_error_string': (_c.c_char_p, [_i32]),
+    'nif_device_count': (_i32, []),
+    'nif_xty_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32]),
+    'nif_xty': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    'nif_cost_dist': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
+    'nif_cost_hf': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
+    'nif_lap_workspace_bytes': (_sz, [_i32]),
+    'nif_lap_solve_f32': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class NifError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C {os.path.dirname(LIB_PATH)}`. There is no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is absent
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib.nif_error_string(status).decode()
+        raise NifError(f'{what} failed with status {status}: {msg}')

@@ -1,0 +1,130 @@
+"""Torch-tensor front end of the C ABI (include/nif.h).
+
+Tensors supply device memory and the current HIP stream; every computation below
+runs in libnif.so.  Inputs must live on a HIP device: there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_DT = {torch.float32: _lib.NIF_F32, torch.float64: _lib.NIF_F64}
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.NifError('libnif ops need tensors on a HIP device (no CPU fallback)')
+
+
+def _mat(t, name):
+    if t.dim() != 2:
+        raise ValueError(f'{name} must be 2-D, got shape {tuple(t.shape)}')
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, trans_b=False, norms=True):
+    """G = A^T B over the rows (f64, n0 x n1) and the squared column norms (f64).
+
+    A: m x n0, B: m x n1 (or n x m when trans_*).  B=None means B is A (symmetric mode).
+    acc: 'f32' (exact-f32 MFMA per row block, f64 across blocks) or 'f64' (f64 MFMA).
+    Returns (G, na, nb); na/nb are None when norms=False.
+    """
+    symmetric = B is None
+    A = _mat(A, 'A')
+    B = A if symmetric else _mat(B, 'B')
+    _need_gpu(A, B)
+    if A.dtype != B.dtype or A.dtype not in _DT:
+        raise TypeError(f'xty needs matching float32/float64 inputs, got {A.dtype} / {B.dtype}')
+    if symmetric:
+        trans_b, relu_b = trans_a, relu_a
+    m = A.shape[1] if trans_a else A.shape[0]
+    mb = B.shape[1] if trans_b else B.shape[0]
+    if m != mb:
+        raise ValueError(f'row counts differ: {m} vs {mb}')
+    n0 = A.shape[0] if trans_a else A.shape[1]
+    n1 = B.shape[0] if trans_b else B.shape[1]
+    accv = _lib.NIF_F64 if (acc == 'f64' or A.dtype == torch.float64) else _lib.NIF_F32
+    flags = ((_lib.NIF_RELU_A if relu_a else 0) | (_lib.NIF_RELU_B if relu_b else 0) |
+             (_lib.NIF_SYMMETRIC if symmetric else 0) | (_lib.NIF_TRANS_A if trans_a else 0) |
+             (_lib.NIF_TRANS_B if trans_b else 0))
+    with torch.cuda.device(A.device):
+        G = torch.empty((n0, n1), dtype=torch.float64, device=A.device)
+        na = torch.empty(n0, dtype=torch.float64, device=A.device) if norms else None
+        nb = torch.empty(n1, dtype=torch.float64, device=A.device) if norms else None
+        nbytes = lib.nif_xty_workspace_bytes(m, n0, n1, accv, flags)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=A.device)
+        check(lib.nif_xty(_ptr(A), _ld(A), _ptr(B), _ld(B), m, n0, n1, _DT[A.dtype], accv, flags,
+                          _ptr(G), n1, _ptr(na), _ptr(nb), _ptr(ws), nbytes, _stream()), 'nif_xty')
+    return G, na, nb
+
+
+def cost_dist(G, na, nb, s0=None, s1=None, colscale=None):
+    """C = scale * sqrt(max(na_i + nb_j - 2 G_ij, 0)) as f32 (see nif_cost_dist)."""
+    _need_gpu(G, na, nb, s0, s1, colscale)
+    n0, n1 = G.shape
+    f32 = lambda t: None if t is None else t.to(device=G.device, dtype=torch.float32).contiguous()
+    s0, s1, colscale = f32(s0), f32(s1), f32(colscale)
+    with torch.cuda.device(G.device):
+        C = torch.empty((n0, n1), dtype=torch.float32, device=G.device)
+        check(lib.nif_cost_dist(_ptr(G), G.stride(0), _ptr(na), _ptr(nb), _ptr(s0), _ptr(s1), _ptr(colscale),
+                                n0, n1, _ptr(C), n1, _stream()), 'nif_cost_dist')
+    return C
+
+
+def cost_hf(G01, pp0, pp1, r0, r1, s0, s1):
+    """HF cost matrix from projected-activation Gram quantities (see nif_cost_hf)."""
+    _need_gpu(G01, pp0, pp1, r0, r1)
+    n0, n1 = G01.shape
+    s0 = s0.to(device=G01.device, dtype=torch.float32).contiguous()
+    s1 = s1.to(device=G01.device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(G01.device):
+        C = torch.empty((n0, n1), dtype=torch.float32, device=G01.device)
+        check(lib.nif_cost_hf(_ptr(G01), G01.stride(0), _ptr(pp0), _ptr(pp1), _ptr(r0), _ptr(r1), _ptr(s0), _ptr(s1),
+                              n0, n1, _ptr(C), n1, _stream()), 'nif_cost_hf')
+    return C
+
+
+def lap_solve(C, duals=False):
+    """Min-cost perfect matching of a square f32 cost matrix on the device.
+
+    Returns col4row (int32, device) -- scipy's ``col_ind`` -- and, with duals=True,
+    also (row4col, u, v).
+    """
+    _need_gpu(C)
+    C = _mat(C, 'C')
+    if C.dtype != torch.float32 or C.shape[0] != C.shape[1]:
+        raise TypeError('lap_solve needs a square float32 matrix')
+    n = C.shape[0]
+    if n > _lib.NIF_LAP_MAX_N:
+        raise _lib.NifError(f'lap_solve: n={n} exceeds NIF_LAP_MAX_N={_lib.NIF_LAP_MAX_N}')
+    with torch.cuda.device(C.device):
+        col = torch.empty(n, dtype=torch.int32, device=C.device)
+        row = torch.empty(n, dtype=torch.int32, device=C.device) if duals else None
+        u = torch.empty(n, dtype=torch.float64, device=C.device) if duals else None
+        v = torch.empty(n, dtype=torch.float64, device=C.device) if duals else None
+        nbytes = lib.nif_lap_workspace_bytes(n)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=C.device)
+        check(lib.nif_lap_solve_f32(_ptr(C), _ld(C), n, _ptr(col), _ptr(row), _ptr(u), _ptr(v), _ptr(ws), nbytes,
+                                    _stream()), 'nif_lap_solve_f32')
+    if duals:
+        return col, row, u, v
+    return col

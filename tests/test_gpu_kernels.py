@@ -1,0 +1,174 @@
+"""-m gpu: the HIP kernels, called through the C ABI, against f64 torch / scipy on the same inputs."""
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import linear_sum_assignment
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the GPU box'
+    from neuron_interpolation_model_fusion_amd import ops as _ops
+    return _ops
+
+
+def _ref_gram(A, B, relu_a=False, relu_b=False):
+    A = A.double().cpu()
+    B = B.double().cpu()
+    if relu_a:
+        A = A.clamp_min(0)
+    if relu_b:
+        B = B.clamp_min(0)
+    return A.T @ B, (A * A).sum(0), (B * B).sum(0)
+
+
+XTY_SHAPES = [
+    (48, 32, 32), (400, 256, 256), (1000, 10, 10), (777, 130, 70), (5000, 384, 384),
+    (6144, 8, 8), (33, 257, 129), (16, 128, 128), (1, 5, 7), (20000, 64, 200),
+]
+
+
+@pytest.mark.parametrize('m,n0,n1', XTY_SHAPES)
+@pytest.mark.parametrize('acc', ['f32', 'f64'])
+def test_xty_matches_f64(ops, m, n0, n1, acc):
+    g = torch.Generator().manual_seed(m * 7 + n0)
+    A = torch.randn(m, n0, generator=g)
+    B = torch.randn(m, n1, generator=g) + 0.5
+    G, na, nb = ops.xty(A.cuda(), B.cuda(), acc=acc)
+    Gr, nar, nbr = _ref_gram(A, B)
+    scale = (nar.sqrt()[:, None] * nbr.sqrt()[None, :])
+    tol = 2e-6 if acc == 'f32' else 1e-12
+    assert ((G.cpu() - Gr).abs() / scale).max().item() < tol
+    assert ((na.cpu() - nar).abs() / nar).max().item() < tol
+    assert ((nb.cpu() - nbr).abs() / nbr).max().item() < tol
+
+
+def test_xty_exact_on_integers(ops):
+    """Asymmetric small-integer data: every product and sum is exact, so any layout slip shows."""
+    m, n0, n1 = 300, 200, 136
+    r = torch.arange(m)[:, None]
+    A = ((r * 3 + torch.arange(n0)[None, :] * 5) % 7 - 3).float()
+    B = ((r * 2 + torch.arange(n1)[None, :] * 11) % 5 - 1).float()
+    for acc in ('f32', 'f64'):
+        G, na, nb = ops.xty(A.cuda(), B.cuda(), acc=acc)
+        Gr, nar, nbr = _ref_gram(A, B)
+        assert torch.equal(G.cpu(), Gr)
+        assert torch.equal(na.cpu(), nar) and torch.equal(nb.cpu(), nbr)
+
+
+@pytest.mark.parametrize('acc', ['f32', 'f64'])
+def test_xty_symmetric_relu_unaligned(ops, acc):
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(901, 300, generator=g)
+    G, na, nb = ops.xty(A.cuda(), None, acc=acc, relu_a=True)
+    Gr, nar, _ = _ref_gram(A, A, True, True)
+    tol = 2e-6 if acc == 'f32' else 1e-12
+    assert ((G.cpu() - Gr).abs().max() / Gr.abs().max()).item() < tol
+    assert torch.allclose(G.cpu(), G.cpu().T, rtol=0, atol=0)
+    assert torch.allclose(na.cpu(), nar, rtol=tol * 10)
+    assert torch.allclose(nb.cpu(), nar, rtol=tol * 10)
+    # odd leading dimension (no 16-byte vector loads) and a column slice
+    Ab = torch.randn(500, 77, generator=g).cuda()
+    view = Ab[:, 3:60]
+    G2, _, _ = ops.xty(view, Ab, acc=acc)
+    Gr2, _, _ = _ref_gram(view, Ab)
+    assert ((G2.cpu() - Gr2).abs().max() / Gr2.abs().max()).item() < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_xty_transposed_operands(ops, dtype):
+    g = torch.Generator().manual_seed(9)
+    At = torch.randn(150, 420, generator=g, dtype=dtype)  # n0 x m
+    B = torch.randn(420, 90, generator=g, dtype=dtype)
+    G, na, nb = ops.xty(At.cuda(), B.cuda(), acc='f64', trans_a=True)
+    Gr = At.double() @ B.double()
+    assert ((G.cpu() - Gr).abs().max() / Gr.abs().max()).item() < 1e-12
+    assert torch.allclose(na.cpu(), (At.double() ** 2).sum(1), rtol=1e-12)
+    # X X^T (dual normal equations): both operands transposed, symmetric
+    G2, _, _ = ops.xty(At.cuda(), None, acc='f64', trans_a=True)
+    Gr2 = At.double() @ At.double().T
+    assert ((G2.cpu() - Gr2).abs().max() / Gr2.abs().max()).item() < 1e-12
+    Bt = B.T.contiguous()
+    G3, _, _ = ops.xty(At.cuda(), Bt.cuda(), acc='f64', trans_a=True, trans_b=True)
+    assert ((G3.cpu() - Gr).abs().max() / Gr.abs().max()).item() < 1e-12
+
+
+def test_cost_dist_and_hf(ops):
+    g = torch.Generator().manual_seed(11)
+    m, n0, n1 = 600, 96, 80
+    A = torch.randn(m, n0, generator=g)
+    B = torch.randn(m, n1, generator=g)
+    s0 = torch.rand(n0, generator=g) + 0.1
+    s1 = torch.rand(n1, generator=g) + 0.1
+    G, na, nb = ops.xty(A.cuda(), B.cuda())
+    C = ops.cost_dist(G, na, nb).cpu()
+    ref = torch.cdist(A.double().T, B.double().T)
+    assert torch.allclose(C.double(), ref, rtol=2e-6)
+    Cg = ops.cost_dist(G, na, nb, s0.cuda(), s1.cuda()).cpu()
+    w = 2 * s0[:, None].double() * s1[None, :].double() / (s0[:, None].double() + s1[None, :].double())
+    assert torch.allclose(Cg.double(), ref * w, rtol=2e-6)
+    # HF closed form against the brute-force definition (hf_kf.py:109-119) on a rank-deficient X
+    d = 40
+    X = torch.randn(m, d, generator=g, dtype=torch.float64)
+    X[:, 5] = X[:, 4]
+    P = X @ torch.linalg.pinv(X)
+    A64, B64 = A.double(), B.double()
+    P0, P1 = P @ A64, P @ B64
+    r0 = ((A64 - P0) ** 2).sum(0)
+    r1 = ((B64 - P1) ** 2).sum(0)
+    Ch = ops.cost_hf((P0.T @ P1).cuda(), (P0 ** 2).sum(0).cuda(), (P1 ** 2).sum(0).cuda(), r0.cuda(), r1.cuda(),
+                     s0.cuda(), s1.cuda()).cpu()
+    ref_h = torch.zeros(n0, n1, dtype=torch.float64)
+    for i in range(n0):
+        pred = (s0[i] * P0[:, i:i + 1] + s1[None, :] * P1) / (s0[i] + s1[None, :])
+        ref_h[i] = s0[i] * (pred - A64[:, i:i + 1]).norm(dim=0) + s1 * (pred - B64).norm(dim=0)
+    assert torch.allclose(Ch.double(), ref_h, rtol=1e-5)
+
+
+def _check_lap(ops, C):
+    n = C.shape[0]
+    col, row, u, v = ops.lap_solve(C.cuda(), duals=True)
+    col = col.cpu().numpy().astype(np.int64)
+    row = row.cpu().numpy()
+    assert sorted(col.tolist()) == list(range(n)), 'not a permutation'
+    assert (row[col] == np.arange(n)).all()
+    Cn = C.double().numpy()
+    r, c = linear_sum_assignment(Cn)
+    opt = Cn[r, c].sum()
+    got = Cn[np.arange(n), col].sum()
+    assert abs(got - opt) <= 1e-9 * max(1.0, abs(opt)), (got, opt)
+    # dual certificate: feasibility and complementary slackness
+    u = u.cpu().numpy()
+    v = v.cpu().numpy()
+    slack = Cn - u[:, None] - v[None, :]
+    assert slack.min() > -1e-9 * max(1.0, np.abs(Cn).max())
+    assert np.abs(slack[np.arange(n), col]).max() < 1e-9 * max(1.0, np.abs(Cn).max())
+    return col, c
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 10, 64, 100, 256, 384, 513, 1024, 1500, 2048, 3000])
+def test_lap_random(ops, n):
+    g = torch.Generator().manual_seed(n)
+    C = torch.rand(n, n, generator=g) * 10
+    col, ref = _check_lap(ops, C)
+    assert (col == ref).all()  # continuous random costs: the optimum is unique
+
+
+def test_lap_planted_and_ties(ops):
+    g = torch.Generator().manual_seed(3)
+    n = 384
+    A = torch.randn(2000, n, generator=g)
+    perm = torch.randperm(n, generator=g)
+    B = A[:, perm] + 0.1 * torch.randn(2000, n, generator=g)
+    C = torch.cdist(A.T, B.T)
+    col, ref = _check_lap(ops, C)
+    assert (col == ref).all()
+    assert (perm[col] == torch.arange(n)).all()
+    # heavy ties: integer costs; only optimality is required
+    Ci = torch.randint(0, 4, (200, 200), generator=g).float()
+    _check_lap(ops, Ci)
+    _check_lap(ops, torch.zeros(50, 50))
+    # negative costs
+    _check_lap(ops, torch.randn(300, 300, generator=g))
