@@ -117,6 +117,21 @@ size_t nif_lap_workspace_bytes(int n);
 int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int32_t* col4row, int32_t* row4col,
                       double* u, double* v, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * nif_refit_gather: weight write-back under a matching,
+ *   out[i][c*sp + e] = a_i * W0[i][c*sp + e] + b_i * W1[rowsrc[i]][colsrc[c]*sp + e]
+ * with a_i = alpha_v ? alpha_v[i] : alpha (same for b).  W0 may be NULL (treated as 0).
+ * rowsrc / colsrc NULL = identity.  All matrices are n_out x (n_in * sp) f32, dense.
+ *   - Git Re-Basin: aligned_w1 = P w1 P_prev^T, importance-weighted average
+ *     (git_rebasin.py:163-213): rowsrc = col_ind, colsrc = previous col_ind, sp = kh*kw.
+ *   - OTFusion with permutation plans (uniform marginals): W_k T_prev diag(1/nu_prev) then
+ *     T^T diag(1/mu), accumulated into the running sum (otfusion.py:261-343):
+ *     rowsrc = row4col, colsrc = previous row4col.
+ * ------------------------------------------------------------------------- */
+int nif_refit_gather(const float* W0, const float* W1, const int32_t* rowsrc, const int32_t* colsrc,
+                     const float* alpha_v, const float* beta_v, float alpha, float beta, int n_out,
+                     int n_in, int sp, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,30 @@ def lap_solve(C, duals=False):
     if duals:
         return col, row, u, v
     return col
+
+
+def refit_gather(W0, W1, rowsrc=None, colsrc=None, alpha=1.0, beta=1.0, sp=1):
+    """out[i, c*sp+e] = a_i W0[i, c*sp+e] + b_i W1[rowsrc[i], colsrc[c]*sp+e] (see nif_refit_gather).
+
+    alpha / beta are floats or per-row f32 tensors; W0 may be None; index tensors are int32.
+    W1 is (n_out, n_in*sp) (any trailing shape is flattened); the result has W1's shape.
+    """
+    _need_gpu(W0, W1, rowsrc, colsrc)
+    shape = W1.shape
+    n_out = shape[0]
+    W1f = W1.reshape(n_out, -1).contiguous().float()
+    width = W1f.shape[1]
+    if width % sp:
+        raise ValueError('row length is not a multiple of sp')
+    W0f = None if W0 is None else W0.reshape(n_out, -1).contiguous().float()
+    dev = W1f.device
+    i32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int32).contiguous()
+    rowsrc, colsrc = i32(rowsrc), i32(colsrc)
+    av = alpha.to(device=dev, dtype=torch.float32).contiguous() if torch.is_tensor(alpha) else None
+    bv = beta.to(device=dev, dtype=torch.float32).contiguous() if torch.is_tensor(beta) else None
+    with torch.cuda.device(dev):
+        out = torch.empty_like(W1f)
+        check(lib.nif_refit_gather(_ptr(W0f), _ptr(W1f), _ptr(rowsrc), _ptr(colsrc), _ptr(av), _ptr(bv),
+                                   0.0 if av is not None else float(alpha), 0.0 if bv is not None else float(beta),
+                                   n_out, width // sp, sp, _ptr(out), _stream()), 'nif_refit_gather')
+    return out.reshape(shape)

@@ -1,0 +1,81 @@
+"""Capture, views and importance dispatch shared by the fusion classes
+(reference: utils/fusion_utils.py:7-111)."""
+import torch
+
+from .model_utils import is_conv_weight
+
+
+def _common_count(models, attr, what):
+    counts = [len(getattr(m, attr)) for m in models]
+    for idx, c in enumerate(counts[1:]):
+        if c != counts[0]:
+            raise ValueError(f'The number of {what} of model 1 is different compared to model {idx + 1}:'
+                             f' {counts[0]} != {c}')
+    return counts[0]
+
+
+def get_num_layers(models):
+    """Common layer count; ValueError on mismatch (fusion_utils.py:7-15)."""
+    return _common_count(models, 'get_ordered_trainable_named_layers', 'layers')
+
+
+def get_num_levels(models):
+    """Common level count; ValueError on mismatch (fusion_utils.py:18-26)."""
+    return _common_count(models, 'get_ordered_trainable_named_levels', 'levels')
+
+
+def initialize_activations(model, activation_dataset):
+    """One hooked forward of all fusion samples (fusion_utils.py:29-35)."""
+    model.remove_hooks()
+    model.register_hooks()
+    with torch.no_grad():
+        model(activation_dataset)
+
+
+def normalize_activations(activations):
+    """Unit L2 norm per neuron (column) (fusion_utils.py:38-40)."""
+    return activations / torch.norm(activations, dim=0, keepdim=True)
+
+
+def normalize_activations_per_sample(activations):
+    """Unit L2 norm per sample (row) (fusion_utils.py:43-45)."""
+    return activations / torch.norm(activations, dim=1, keepdim=True)
+
+
+def get_layer_weight(model, layer):
+    """Detached copy of a layer's weight; conv weights as (out, in, kh*kw) (fusion_utils.py:48-57)."""
+    weight = model.get_ordered_trainable_named_layers[layer].weight.data.detach().clone()
+    conv = is_conv_weight(weight)
+    return (weight.flatten(2) if conv else weight), conv
+
+
+def get_layer_width(model, layer_idx):
+    return model.get_ordered_trainable_named_layers[layer_idx].weight.data.shape[0]
+
+
+def get_preactivations_of_layer(model, target_model, layer):
+    """(rows, width) pre-activations of both models; conv rows are (b, h, w) (fusion_utils.py:68-82)."""
+    _, a = model.get_inputs_and_preactivations(layer_idx=layer)
+    _, b = target_model.get_inputs_and_preactivations(layer_idx=layer)
+    if a.dim() == 4:
+        a = a.permute(1, 0, 2, 3).flatten(1).T
+        b = b.permute(1, 0, 2, 3).flatten(1).T
+    return a, b
+
+
+def compute_neuron_importance_scores(method, model, idx, X, y, fusion_logic, batch_size=50):
+    """Per-neuron importance of a layer or level, on the CPU (fusion_utils.py:85-111).
+
+    Only 'uniform' is built: conductance / deeplift / featureablation are captum
+    attributions (utils/neuron_importance.py), outside the hot path.
+    """
+    assert fusion_logic in ['layer', 'level'], f'Invalid fusion logic: {fusion_logic}'
+    if fusion_logic == 'layer':
+        width = get_layer_width(model, idx)
+    else:
+        width = model.get_ordered_trainable_named_levels[idx].output_width
+    if method == 'uniform':
+        return torch.ones(width)
+    raise NotImplementedError(
+        f"neuron importance method '{method}' needs captum attributions (reference utils/neuron_importance.py); "
+        "only 'uniform' is available in this build")

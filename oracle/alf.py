@@ -1,0 +1,111 @@
+"""Oracle for ALF's neuron clustering and target matching (reference fusion_algorithms/alf.py).
+Test infrastructure: see oracle/__init__.py."""
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from neuron_interpolation_model_fusion_amd.utils.fusion_utils import normalize_activations_per_sample
+
+
+def flatten_acts(acts):
+    """(rows, width) view of level outputs: ViT [B, h, seq] -> (B*seq, h); conv [B, C, H, W] ->
+    (B*W*H, C), W-major. alf.py:104-115."""
+    if acts.dim() == 2:
+        return acts
+    if acts.dim() == 3:
+        return acts.permute(0, 2, 1).reshape(-1, acts.shape[1])
+    if acts.dim() == 4:
+        return acts.permute(0, 3, 2, 1).reshape(-1, acts.shape[1])
+    raise ValueError(f'Invalid shape for activations: {acts.shape}. Expected a 2D, 3D or 4D tensor.')
+
+
+def unflatten_target(T, k, height, width, seqlen):
+    """alf.py:117-124."""
+    if height and width:
+        return T.reshape(-1, width, height, k).permute(0, 3, 2, 1)
+    if seqlen:
+        return T.reshape(-1, seqlen, k).permute(0, 2, 1)
+    return T
+
+
+def centroids(k, assignment, rows, weights):
+    """Weighted mean of the member rows of every NON-EMPTY cluster, label order (compacted).
+    alf.py:145-169."""
+    members = [[] for _ in range(k)]
+    for i, c in enumerate(assignment):
+        members[int(c)].append(i)
+    out = []
+    for idx in members:
+        if not idx:
+            continue
+        wn = weights[idx] / torch.sum(weights[idx])
+        out.append(torch.sum(rows[idx] * wn[:, None], axis=0))
+    return torch.stack(out)
+
+
+def match_T_to_X(X, T, W, chunk=64):
+    """alf.py:126-143: cost[i][j] = ||X[:, i] - T[:, j]|| * W[j], LSA, aligned_T[:, r] = T[:, c]."""
+    X = flatten_acts(X)
+    n, k = X.shape[1], T.shape[1]
+    cost = torch.zeros(n, k)
+    for i0 in range(0, n, chunk):
+        i1 = min(i0 + chunk, n)
+        cost[i0:i1] = torch.norm(X[:, i0:i1].unsqueeze(2) - T.unsqueeze(1), dim=0) * W
+    r, c = linear_sum_assignment(cost.numpy())
+    out = torch.zeros_like(T)
+    out[:, r] = T[:, c]
+    return out, cost, c
+
+
+def kmeans_v2(level_acts, k, sample_weight, normalize, init_with_2nd, num_runs=1, level_X=None,
+              align_skip=False, stats=None):
+    """ALFusion._k_means_v2 on already-captured level outputs (one tensor per model). alf.py:171-298."""
+    height = width = seqlen = 0
+    if level_acts[0].dim() == 4:
+        height, width = level_acts[0].shape[2], level_acts[0].shape[3]
+    elif level_acts[0].dim() == 3:
+        seqlen = level_acts[0].shape[2]
+    do_match = align_skip and level_X is not None and level_acts[0].shape == level_X.shape
+    flat = [flatten_acts(a) for a in level_acts]
+    acts = torch.cat(flat, dim=1)
+    km = torch.cat([normalize_activations_per_sample(a) for a in flat], dim=1) if normalize else acts
+    best_cost, best = float('inf'), None
+    for _ in range(num_runs):
+        cent = km[:, k:2 * k].T if init_with_2nd else km[:, :k].T
+        assignment = torch.min(torch.cdist(cent, km.T, p=2), dim=0)[1]
+        prev = torch.ones(len(assignment)) * (-1)
+        costs = []
+        while (prev != assignment).any():
+            if stats is not None:
+                stats['lloyd_steps'] = stats.get('lloyd_steps', 0) + 1
+            prev = assignment
+            cent = centroids(k, assignment, km.T, sample_weight)
+            nearest, assignment = torch.min(torch.cdist(cent, km.T, p=2), dim=0)
+            # empty-cluster repair: never empties a singleton cluster (alf.py:248-262)
+            counts = torch.bincount(assignment, minlength=k)
+            missing = set(range(k)) - set(assignment.tolist())
+            while missing:
+                c = missing.pop()
+                far = torch.max(nearest, dim=0)[1]
+                if counts[assignment[far].item()] == 1:
+                    nearest[far] = float('-inf')
+                    missing.add(c)
+                    continue
+                counts[assignment[far].item()] -= 1
+                assignment[far] = c
+                nearest[far] = float('-inf')
+            nearest = torch.where(nearest == float('-inf'), torch.tensor(0.0), nearest)
+            cost = torch.sum(nearest * sample_weight)
+            if len(costs) >= 3 and cost >= costs[-3]:
+                break
+            costs.append(cost)
+        cent = centroids(k, assignment, km.T, sample_weight)
+        total = float(torch.sum(torch.min(torch.cdist(cent, km.T, p=2), dim=0)[0] * sample_weight))
+        if total < best_cost:
+            best, best_cost = assignment, total
+    T = centroids(k, best, acts.T, sample_weight).T  # from the UN-normalised activations (alf.py:288)
+    if do_match:
+        tot = torch.zeros(T.shape[1])
+        for i in range(best.shape[0]):
+            tot[best[i]] += sample_weight[i]
+        T, _, _ = match_T_to_X(level_X, T, tot)
+    return unflatten_target(T, k, height, width, seqlen), best

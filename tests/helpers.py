@@ -1,0 +1,53 @@
+"""Shared test helpers: rebuild the fixture models (package classes) from the golden npz files."""
+import os
+
+import numpy as np
+import torch
+
+from neuron_interpolation_model_fusion_amd.models import MLPNet, VGG
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def _state(z, prefix):
+    return {k[len(prefix) + 1:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix + '.')}
+
+
+def build_models(name, z, device='cpu'):
+    n = len({k.split('.')[0] for k in z.files if k.startswith('sd')})
+    models = []
+    for k in range(n):
+        sd = _state(z, f'sd{k}')
+        if name.startswith('mlp'):
+            hid, inp = sd['level1.1.weight'].shape
+            out = [v for kk, v in sd.items() if kk.startswith('level2') and kk.endswith('weight')][0].shape[0]
+            m = MLPNet(inp, hid, out, use_bias=True, use_activations=False)
+        else:
+            cfg = [c if c == 'M' else int(c) for c in z['cfg'].tolist()]
+            VGG.cfg['VGG_tiny'] = cfg
+            m = VGG('VGG_tiny', 10, (3, 32, 32), batch_norm=False, use_bias=True, use_activations=False)
+        m.load_state_dict(sd)
+        models.append(m.eval().to(device))
+    X = torch.from_numpy(z['X'].astype(np.float32)).to(device)
+    return models, X
+
+
+def fused_state(z, tag):
+    return _state(z, f'{tag}.fused')
+
+
+def assert_state_close(model, expected, rtol=1e-3, atol=1e-5):
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert set(got) == set(expected)
+    for k in expected:
+        scale = expected[k].abs().max().item() + 1e-12
+        err = (got[k] - expected[k]).abs().max().item()
+        assert err <= rtol * scale + atol, f'{k}: max abs err {err:.3e} vs scale {scale:.3e}'
+
+
+def n_layers(z, tag):
+    return len([k for k in z.files if k.startswith(f'{tag}.col')])
