@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- fused levels/sec of the per-level matching-and-refit path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], SURVEY section 8d "C2"): one OTFusion activation-mode
+level at ViT widths on synthetic activations -- m = 5000 samples x 65 tokens = 325 000 rows,
+width n = 384, uniform marginals (there is no ViT layer path in the reference, SURVEY D2, so
+the level is measured on activations of that shape).  One step = one level:
+  ground metric  : nif_xty (f32 MFMA cross-Gram A_k^T A_f + column norms) -> nif_cost_dist
+  assignment     : nif_lap_solve_f32 (exact plan P/n for uniform marginals)
+  refit          : nif_refit_gather (edge alignment with the previous plan, barycentric
+                   projection, average with the target) for the weight and the bias.
+Inputs are resident in HBM before the timed region.  With N > 1 the fusion samples (rows) are
+sharded over the ranks ("strong" scaling: the level is fixed, rows per GPU = m / N); each rank
+builds its partial [G | na | nb] buffer and one RCCL all-reduce (sum, f64) per level combines
+them; the n x n assignment and the refit are replicated.
+
+The JSON line also carries
+  roofline     : the dominant kernel (nif::xty_kernel, f32 MFMA): algorithmic flops
+                 2*m_local*n*n per launch / its mean duration from HIP events recorded on the
+                 launch stream inside the library, against the 157.3 TFLOP/s dense f32 MFMA peak;
+  cpu_baseline : the oracle (CPU restatement of otfusion.py's level: torch.cdist on the CPU,
+                 scipy assignment, dense T-matrix refit) timed on this host, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M_ROWS = 5000 * 65
+WIDTH = 384
+FAN_IN = 384
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def make_level(m_local, n, fan_in, device, seed):
+    """Synthetic level: model-k activations are a noisy column permutation of the target's."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    gp = torch.Generator().manual_seed(1234)  # the permutation is the same on every rank
+    perm = torch.randperm(n, generator=gp).to(device)
+    act_f = torch.randn(m_local, n, device=device, generator=g)
+    act_k = act_f[:, perm] * 0.9 + 0.3 * torch.randn(m_local, n, device=device, generator=g)
+    gw = torch.Generator(device=device).manual_seed(99)
+    w_k = torch.randn(n, fan_in, device=device, generator=gw)
+    w_f = torch.randn(n, fan_in, device=device, generator=gw)
+    b_k = torch.randn(n, 1, device=device, generator=gw)
+    b_f = torch.randn(n, 1, device=device, generator=gw)
+    prev = torch.randperm(fan_in, generator=gp).to(device=device, dtype=torch.int32)
+    return dict(act_k=act_k, act_f=act_f, w_k=w_k, w_f=w_f, b_k=b_k, b_f=b_f, prev=prev, perm=perm)
+
+
+def level_step(ops, lv, dist=None):
+    """One fused level on the GPU; returns (col4row, fused weight, fused bias)."""
+    n = lv['act_k'].shape[1]
+    G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32')
+    if dist is not None:
+        packed = torch.cat([G.reshape(-1), na, nb])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        G, na, nb = packed[:n * n].view(n, n), packed[n * n:n * n + n], packed[n * n + n:]
+    C = ops.cost_dist(G, na, nb)
+    col, row, _, _ = ops.lap_solve(C, duals=True)
+    # T = P/n, so T^T diag(1/mu) = P^T: target neuron j receives model-k neuron row4col[j]
+    w = ops.refit_gather(lv['w_f'], lv['w_k'], rowsrc=row, colsrc=lv['prev'], alpha=0.5, beta=0.5)
+    b = ops.refit_gather(lv['b_f'], lv['b_k'], rowsrc=row, alpha=0.5, beta=0.5)
+    return col, w, b
+
+
+def cpu_level(lv_cpu):
+    """The same level through the oracle's op sequence (otfusion.py:261-343) on the CPU."""
+    from oracle import otfusion as o
+    n = lv_cpu['act_k'].shape[1]
+    mu = torch.ones(n) / n
+    C = o.ground_metric_acts(lv_cpu['act_k'], lv_cpu['act_f'])
+    T = o.emd(mu, mu, C)
+    fan_in = lv_cpu['w_k'].shape[1]
+    Tp = torch.zeros(fan_in, fan_in)
+    Tp[lv_cpu['prev'].long(), torch.arange(fan_in)] = 1.0  # previous plan times diag(1/nu_prev)
+    edges = lv_cpu['w_k'] @ Tp
+    Tc = T.T @ torch.diag(1 / mu)
+    w = (lv_cpu['w_f'] + Tc @ edges) / 2
+    b = (lv_cpu['b_f'] + Tc @ lv_cpu['b_k']) / 2
+    return T, w, b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--rows', type=int, default=M_ROWS)
+    ap.add_argument('--width', type=int, default=WIDTH)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback for the product path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+    from neuron_interpolation_model_fusion_amd import ops
+
+    n = args.width
+    m_total = args.rows
+    lo = m_total * rank // world
+    hi = m_total * (rank + 1) // world
+    lv = make_level(hi - lo, n, FAN_IN if n == WIDTH else n, device, seed=1000 + rank)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = level_step(ops, lv, dist)
+    sync()
+    ops.profile_collect(ops.PROF_XTY)
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = level_step(ops, lv, dist)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.profile_enable(False)
+    kernel_ms, launches = ops.profile_collect(ops.PROF_XTY)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the planted permutation is recovered (N = 1: exactly this rank's data; N > 1: summed Gram)
+    col = out[0].long()
+    recovered = bool((col == lv['perm']).all())  # model-k neuron i is target neuron perm[i] plus noise
+
+    result = None
+    if rank == 0:
+        flops = 2.0 * (hi - lo) * n * n
+        avg_ms = kernel_ms / max(launches, 1)
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if launches else None
+        result = {
+            'metric': 'fused levels/sec',
+            'value': args.steps / elapsed,
+            'unit': 'levels/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'strong',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'C2 OTFusion activation-mode level at ViT width: m={m_total} rows (5000 samples x 65 '
+                            f'tokens), n={n}, uniform marginals; ground-metric Gram + exact assignment + refit',
+                'rows_per_gpu': hi - lo,
+                'parallelism': f'rows sharded over {world} GPU(s), one f64 all-reduce of [G|na|nb] per level'
+                               if world > 1 else 'single GPU',
+                'planted_permutation_recovered': recovered,
+            },
+            'roofline': {
+                'kernel': 'nif::xty_kernel<float, MmaF32> (v_mfma_f32_32x32x2_f32)',
+                'bound': 'mfma',
+                'achieved': achieved,
+                'peak': F32_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': (achieved / F32_MFMA_PEAK_TFLOPS) if achieved else None,
+                'traffic': None,
+                'avg_kernel_ms': avg_ms,
+                'launches': launches,
+                'algorithmic_flops_per_launch': flops,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            lv_cpu = {k: v.cpu() for k, v in lv.items()}
+            cores = torch.get_num_threads()
+            cpu_level(lv_cpu)  # warm-up (thread pool, allocator)
+            reps, t_cpu = 0, 0.0
+            while reps < 3 or (t_cpu < 10.0 and reps < 20):
+                t1 = time.perf_counter()
+                T, w_ref, b_ref = cpu_level(lv_cpu)
+                t_cpu += time.perf_counter() - t1
+                reps += 1
+            # the GPU result is checked against the oracle on the same inputs while we are here
+            w_err = float((out[1].cpu() - w_ref).abs().max())
+            same_plan = bool((T.argmax(dim=1) == out[0].cpu().long()).all())
+            result['cpu_baseline'] = {
+                'value': reps / t_cpu,
+                'unit': 'levels/s',
+                'cores': cores,
+                'kind': 'port',
+                'sample': f'{reps} repetitions of the same full level (m={m_total}, n={n}) through oracle/otfusion.py '
+                          f'(torch.cdist on CPU + scipy assignment + dense refit)',
+                'gpu_matches_oracle': same_plan and w_err < 1e-5,
+            }
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

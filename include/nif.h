@@ -51,6 +51,22 @@ const char* nif_error_string(int code);
 int nif_device_count(void);
 
 /* ---------------------------------------------------------------------------
+ * Optional kernel timing for bench.py's roofline line: when enabled, the entry points
+ * record HIP events on the launch stream around their dominant kernel.  Slots:
+ * NIF_PROF_XTY = the MFMA cross-Gram kernel of nif_xty, NIF_PROF_LAP = the augmenting
+ * kernel of nif_lap_solve_f32, NIF_PROF_KMEANS = the Lloyd reduction kernel.
+ * nif_profile_collect synchronises on the recorded events (host blocks), returns the
+ * summed milliseconds and launch count of a slot and clears it.  No reference counterpart
+ * (the reference only prints time.time() deltas, hf_kf.py:211-214,245-247).
+ * ------------------------------------------------------------------------- */
+#define NIF_PROFILE_SLOTS 4
+#define NIF_PROF_XTY 0
+#define NIF_PROF_LAP 1
+#define NIF_PROF_KMEANS 2
+void nif_profile_enable(int on);
+int nif_profile_collect(int slot, double* total_ms, int64_t* launches);
+
+/* ---------------------------------------------------------------------------
  * nif_xty: G = A^T B summed over the m sample rows, plus the squared column
  * norms na[i] = sum_r A[r][i]^2, nb[j] = sum_r B[r][j]^2.
  *

@@ -7,6 +7,11 @@ import fails loudly, and every op raises on a non-zero status.
 import ctypes
 import os
 
+# torch first: libnif.so must bind to the HIP runtime torch has already loaded.  Loading the
+# system libamdhip64 before torch's own copy puts two runtimes in one process and the second
+# one reports "no ROCm-capable device".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libnif.so')
 
@@ -22,6 +27,8 @@ SIGNATURES = {
     'nif_version': (_i32, []),
     'nif_error_string': (_c.c_char_p, [_i32]),
     'nif_device_count': (_i32, []),
+    'nif_profile_enable': (None, [_i32]),
+    'nif_profile_collect': (_i32, [_i32, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
     'nif_xty_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32]),
     'nif_xty': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     'nif_cost_dist': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 namespace nif {
 
@@ -20,7 +21,20 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
   return x;
 }
 
-static inline int launch_ok() { return hipGetLastError() == hipSuccess; }
+// hipGetLastError() is per-thread state shared with every other HIP user in the process (torch's
+// event polling leaves hipErrorNotReady behind), so entry points clear it first and read it after
+// their own launches.
+static inline void clear_err() { (void)hipGetLastError(); }
+static inline int launch_ok() {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) fprintf(stderr, "[libnif] HIP error after launch: %s\n", hipGetErrorString(e));
+  return e == hipSuccess;
+}
+
+// Optional per-kernel timing (nif_profile_enable): HIP events recorded on the launch stream
+// around the dominant kernel of an entry point.  No-ops unless enabled.
+void prof_begin(int slot, hipStream_t st);
+void prof_end(int slot, hipStream_t st);
 
 }  // namespace nif
 

@@ -22,3 +22,71 @@ extern "C" int nif_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return NIF_ERR_NO_DEVICE;
   return n;
 }
+
+// ---- optional kernel timing -------------------------------------------------------
+#include <mutex>
+#include <vector>
+
+#include "nif_common.h"
+
+namespace nif {
+namespace {
+struct Span {
+  int slot;
+  hipEvent_t a, b;
+};
+std::mutex g_mu;
+bool g_enabled = false;
+std::vector<Span> g_spans;
+hipEvent_t g_open[NIF_PROFILE_SLOTS];
+}  // namespace
+
+void prof_begin(int slot, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_enabled || slot < 0 || slot >= NIF_PROFILE_SLOTS) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  g_open[slot] = e;
+}
+
+void prof_end(int slot, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_enabled || slot < 0 || slot >= NIF_PROFILE_SLOTS || !g_open[slot]) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  g_spans.push_back(Span{slot, g_open[slot], e});
+  g_open[slot] = nullptr;
+}
+}  // namespace nif
+
+extern "C" void nif_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(nif::g_mu);
+  nif::g_enabled = on != 0;
+}
+
+extern "C" int nif_profile_collect(int slot, double* total_ms, int64_t* launches) {
+  if (!total_ms || !launches || slot < 0 || slot >= NIF_PROFILE_SLOTS) return NIF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(nif::g_mu);
+  double tot = 0.0;
+  int64_t cnt = 0;
+  std::vector<nif::Span> keep;
+  for (auto& s : nif::g_spans) {
+    if (s.slot != slot) {
+      keep.push_back(s);
+      continue;
+    }
+    float ms = 0.f;
+    if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      tot += ms;
+      ++cnt;
+    }
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  nif::g_spans.swap(keep);
+  *total_ms = tot;
+  *launches = cnt;
+  return NIF_OK;
+}

@@ -58,6 +58,7 @@ extern "C" int nif_cost_dist(const double* G, int64_t ldg, const double* na, con
   if (!G || !na || !nb || !C || n0 <= 0 || n1 <= 0 || ldg < n1 || ldc < n1) return NIF_ERR_INVALID_ARG;
   if ((s0 == nullptr) != (s1 == nullptr)) return NIF_ERR_INVALID_ARG;
   dim3 grid((n1 + 255) / 256, n0);
+  nif::clear_err();
   hipLaunchKernelGGL(nif::cost_dist_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G, ldg, na, nb,
                      s0, s1, colscale, n0, n1, C, ldc);
   return nif::launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
@@ -69,6 +70,7 @@ extern "C" int nif_cost_hf(const double* G01, int64_t ldg, const double* pp0, co
   if (!G01 || !pp0 || !pp1 || !r0 || !r1 || !s0 || !s1 || !C || n0 <= 0 || n1 <= 0 || ldg < n1 || ldc < n1)
     return NIF_ERR_INVALID_ARG;
   dim3 grid((n1 + 255) / 256, n0);
+  nif::clear_err();
   hipLaunchKernelGGL(nif::cost_hf_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G01, ldg, pp0,
                      pp1, r0, r1, s0, s1, n0, n1, C, ldc);
   return nif::launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;

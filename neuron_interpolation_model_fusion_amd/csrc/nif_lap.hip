@@ -286,6 +286,7 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int32_t* co
   const LapWs w = lap_ws(n);
   if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  clear_err();
   unsigned char* b = reinterpret_cast<unsigned char*>(ws);
   float* part = reinterpret_cast<float*>(b + w.off_part);
   double* uu = u ? u : reinterpret_cast<double*>(b + w.off_u);
@@ -307,11 +308,13 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int32_t* co
   int threads = ((n + cpt - 1) / cpt + 63) / 64 * 64;
   if (threads > 1024) return NIF_ERR_UNSUPPORTED;
   const size_t lds = (size_t)((3 * n + 3) & ~3) * sizeof(int) + 32 * sizeof(double) + 64 * sizeof(int);
+  prof_begin(NIF_PROF_LAP, st);
   switch (cpt) {
     case 1: launch_augment<1>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); break;
     case 2: launch_augment<2>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); break;
     case 4: launch_augment<4>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); break;
     default: launch_augment<8>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); break;
   }
+  prof_end(NIF_PROF_LAP, st);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }

@@ -36,6 +36,7 @@ extern "C" int nif_refit_gather(const float* W0, const float* W1, const int32_t*
   if (!W1 || !out || n_out <= 0 || n_in <= 0 || sp <= 0) return NIF_ERR_INVALID_ARG;
   const int64_t width = (int64_t)n_in * sp;
   dim3 grid((unsigned)((width + 255) / 256), n_out);
+  nif::clear_err();
   hipLaunchKernelGGL(nif::refit_gather_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W0, W1,
                      rowsrc, colsrc, alpha_v, beta_v, alpha, beta, n_out, n_in, sp, out);
   return nif::launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;

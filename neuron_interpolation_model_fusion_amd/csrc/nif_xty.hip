@@ -501,6 +501,7 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
   const size_t need = align256(pl.slab_bytes) + align256(pl.nsa_bytes) + align256(pl.nsb_bytes);
   if (!ws || ws_bytes < need) return NIF_ERR_WORKSPACE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  clear_err();
 
   const size_t esz_in = in_dtype == NIF_F64 ? 8 : 4;
   XtyArgs a;
@@ -519,10 +520,12 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
 
   const int nblocks = pl.ntiles * pl.splits;
   const size_t lds = (size_t)2 * 2 * BK * LDS_LD * esz_in;
+  prof_begin(NIF_PROF_XTY, st);
   if (in_dtype == NIF_F32 && acc == NIF_F32) launch_variant<float, MmaF32>(a, nblocks, lds, st);
   else if (in_dtype == NIF_F32) launch_variant<float, MmaF64>(a, nblocks, lds, st);
   else launch_variant<double, MmaF64>(a, nblocks, lds, st);
-  if (hipGetLastError() != hipSuccess) return NIF_ERR_LAUNCH;
+  prof_end(NIF_PROF_XTY, st);
+  if (!launch_ok()) return NIF_ERR_LAUNCH;
 
   const int sym = (flags & NIF_SYMMETRIC) ? 1 : 0;
   dim3 rg((n1 + 255) / 256, n0);
@@ -541,6 +544,6 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
     if (nb) hipLaunchKernelGGL((xty_norm_reduce_kernel<double>), dim3((n1 + 255) / 256), dim3(256), 0, st,
                                sym ? (const double*)nsa : (const double*)nsb, pl.splits, n1, sym ? pl.n0p : pl.n1p, nb);
   }
-  if (hipGetLastError() != hipSuccess) return NIF_ERR_LAUNCH;
+  if (!launch_ok()) return NIF_ERR_LAUNCH;
   return NIF_OK;
 }

@@ -155,3 +155,17 @@ def refit_gather(W0, W1, rowsrc=None, colsrc=None, alpha=1.0, beta=1.0, sp=1):
                                    0.0 if av is not None else float(alpha), 0.0 if bv is not None else float(beta),
                                    n_out, width // sp, sp, _ptr(out), _stream()), 'nif_refit_gather')
     return out.reshape(shape)
+
+
+PROF_XTY, PROF_LAP, PROF_KMEANS = 0, 1, 2
+
+
+def profile_enable(on=True):
+    lib.nif_profile_enable(1 if on else 0)
+
+
+def profile_collect(slot):
+    """(total milliseconds, launches) of the events recorded for a slot since the last collect."""
+    ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+    check(lib.nif_profile_collect(slot, ctypes.byref(ms), ctypes.byref(cnt)), 'nif_profile_collect')
+    return ms.value, cnt.value
