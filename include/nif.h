@@ -127,10 +127,19 @@ int nif_cost_hf(const double* G01, int64_t ldg, const double* pp0, const double*
  * row4col (n), u (n), v (n) are optional outputs (NULL to skip): the dual
  * certificate u[i] + v[j] <= C[i][j] with equality on matched pairs.
  * n <= NIF_LAP_MAX_N.  Costs must be finite.
- * ------------------------------------------------------------------------- */
+ *
+ * flags = 0: fastest path (parallel dual initialisation, then augmentation of the rows
+ *   left free).  Any optimal matching may come back when the optimum is not unique.
+ * flags = NIF_LAP_SCIPY_ORDER: replays scipy's rectangular_lsap order exactly -- zero
+ *   initial duals, rows augmented in index order, and its tie rule between columns of
+ *   equal distance (first in its `remaining` vector unless a free column ties) -- so
+ *   that cost matrices with exact structural ties (dead ReLU neurons give identical
+ *   rows / columns) yield scipy's own matching.  Slower: n augmentations instead of a few.
+ */
 #define NIF_LAP_MAX_N 8192
+#define NIF_LAP_SCIPY_ORDER 1
 size_t nif_lap_workspace_bytes(int n);
-int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int32_t* col4row, int32_t* row4col,
+int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
                       double* u, double* v, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libnif.so')
 NIF_F32, NIF_F64 = 0, 1
 NIF_RELU_A, NIF_RELU_B, NIF_SYMMETRIC, NIF_TRANS_A, NIF_TRANS_B = 1, 2, 4, 8, 16
 NIF_LAP_MAX_N = 8192
+NIF_LAP_SCIPY_ORDER = 1
 
 _c = ctypes
 _vp, _i32, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -34,7 +35,7 @@ SIGNATURES = {
     'nif_cost_dist': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'nif_cost_hf': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'nif_lap_workspace_bytes': (_sz, [_i32]),
-    'nif_lap_solve_f32': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nif_lap_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nif_refit_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32, _vp, _vp]),
 }
 

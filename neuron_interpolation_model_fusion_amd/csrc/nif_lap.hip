@@ -95,7 +95,29 @@ __device__ __forceinline__ bool lap_better(double v, int f, int j, double bv, in
   return j < bj;
 }
 
-template <int CPT>
+// scipy-order variant (rectangular_lsap.cpp, augmenting_path): the sequential scan over its
+// `remaining` vector keeps the FIRST column of minimal distance, except that every later FREE
+// column of equal distance replaces the incumbent -- i.e. among the minima: the free column of
+// highest position if any is free, else the column of lowest position.  p = position of the
+// column in `remaining`.
+__device__ __forceinline__ bool lap_better_scipy(double v, int f, int p, double bv, int bf, int bp) {
+  if (v < bv) return true;
+  if (v > bv) return false;
+  if (f != bf) return f > bf;
+  return f ? (p > bp) : (p < bp);
+}
+
+__global__ void lap_zero_init_kernel(int n, double* __restrict__ u, double* __restrict__ v, int* __restrict__ col4row,
+                                     int* __restrict__ row4col) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  u[t] = 0.0;
+  v[t] = 0.0;
+  col4row[t] = -1;
+  row4col[t] = -1;
+}
+
+template <int CPT, bool SCIPY>
 __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restrict__ C, int64_t ldc, int n,
                                                            double* __restrict__ u, double* __restrict__ vg,
                                                            int* __restrict__ col4row_g, int* __restrict__ row4col_g) {
@@ -103,9 +125,11 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
   int* path = lap_sm;
   int* row4col = lap_sm + n;
   int* col4row = lap_sm + 2 * n;
-  double* redv = reinterpret_cast<double*>(lap_sm + ((3 * n + 3) & ~3));  // [2][16]
-  int* redj = reinterpret_cast<int*>(redv + 32);                           // [2][16]
-  int* redf = redj + 32;                                                   // [2][16]
+  int* remaining = lap_sm + 3 * n;  // position -> column (scipy-order mode only)
+  double* redv = reinterpret_cast<double*>(lap_sm + (((SCIPY ? 4 : 3) * n + 3) & ~3));  // [2][16]
+  int* redj = reinterpret_cast<int*>(redv + 32);                                         // [2][16]
+  int* redf = redj + 32;                                                                 // [2][16]
+  int* redp = redf + 32;                                                                 // [2][16]
 
   const int T = blockDim.x;
   const int tid = threadIdx.x;
@@ -131,8 +155,15 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
     if (col4row[cur] != -1) continue;  // same LDS word for every thread: uniform
 
     unsigned scanned = 0;
+    int pos[CPT];
+    int num_remaining = n;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) spc[c] = INFINITY;
+    for (int c = 0; c < CPT; ++c) {
+      spc[c] = INFINITY;
+      const int j = tid + c * T;
+      pos[c] = n - 1 - j;  // scipy fills `remaining` in reverse order
+      if (SCIPY && j < n) remaining[n - 1 - j] = j;
+    }
     int i = cur;
     double minval = 0.0;
     int sink = -1;
@@ -141,7 +172,7 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
       const double ui = u[i];
       const float* __restrict__ crow = C + (int64_t)i * ldc;
       double bv = INFINITY;
-      int bj = INT_MAX, bf = 0;
+      int bj = INT_MAX, bf = 0, bp = 0;
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
         const int j = tid + c * T;
@@ -152,10 +183,12 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
             path[j] = i;
           }
           const int f = row4col[j] == -1 ? 1 : 0;
-          if (lap_better(spc[c], f, j, bv, bf, bj)) {
+          if (SCIPY ? (bj == INT_MAX || lap_better_scipy(spc[c], f, pos[c], bv, bf, bp))
+                    : lap_better(spc[c], f, j, bv, bf, bj)) {
             bv = spc[c];
             bf = f;
             bj = j;
+            bp = pos[c];
           }
         }
       }
@@ -164,10 +197,13 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
         const double ov = shfl_xor_f64(bv, o);
         const int oj = __shfl_xor(bj, o, 64);
         const int of = __shfl_xor(bf, o, 64);
-        if (lap_better(ov, of, oj, bv, bf, bj)) {
+        const int op = __shfl_xor(bp, o, 64);
+        if (oj != INT_MAX && (SCIPY ? (bj == INT_MAX || lap_better_scipy(ov, of, op, bv, bf, bp))
+                                    : lap_better(ov, of, oj, bv, bf, bj))) {
           bv = ov;
           bf = of;
           bj = oj;
+          bp = op;
         }
       }
       const int pb = (step & 1) * 16;
@@ -176,23 +212,38 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
         redv[pb + wave] = bv;
         redj[pb + wave] = bj;
         redf[pb + wave] = bf;
+        redp[pb + wave] = bp;
       }
       __syncthreads();
       bv = redv[pb];
       bj = redj[pb];
       bf = redf[pb];
+      bp = redp[pb];
       for (int w = 1; w < nw; ++w) {
         const double ov = redv[pb + w];
-        const int oj = redj[pb + w], of = redf[pb + w];
-        if (lap_better(ov, of, oj, bv, bf, bj)) {
+        const int oj = redj[pb + w], of = redf[pb + w], op = redp[pb + w];
+        if (oj != INT_MAX && (SCIPY ? (bj == INT_MAX || lap_better_scipy(ov, of, op, bv, bf, bp))
+                                    : lap_better(ov, of, oj, bv, bf, bj))) {
           bv = ov;
           bf = of;
           bj = oj;
+          bp = op;
         }
       }
-      if (bj == INT_MAX) break;  // no finite candidate left (non-finite costs): give up on this row
+      if (bj == INT_MAX || !(bv < INFINITY)) break;  // no finite candidate (non-finite costs): give up on this row
       minval = bv;
       const int inext = row4col[bj];
+      if (SCIPY) {
+        // remaining[index] = remaining[--num_remaining]
+        --num_remaining;
+        const int last = remaining[num_remaining];
+        if (last != bj) {
+          if (tid == 0) remaining[bp] = last;
+#pragma unroll
+          for (int c = 0; c < CPT; ++c)
+            if (tid + c * T == last) pos[c] = bp;
+        }
+      }
       if (inext == -1) {
         sink = bj;
         break;
@@ -263,10 +314,10 @@ static LapWs lap_ws(int n) {
   return w;
 }
 
-template <int CPT>
+template <int CPT, bool SCIPY>
 static void launch_augment(int threads, size_t lds, hipStream_t st, const float* C, int64_t ldc, int n, double* u,
                            double* v, int* c4r, int* r4c) {
-  auto kfn = lap_augment_kernel<CPT>;
+  auto kfn = lap_augment_kernel<CPT, SCIPY>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(1), dim3(threads), lds, st, C, ldc, n, u, v, c4r, r4c);
 }
@@ -278,8 +329,8 @@ extern "C" size_t nif_lap_workspace_bytes(int n) {
   return nif::lap_ws(n).total;
 }
 
-extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int32_t* col4row, int32_t* row4col, double* u,
-                                 double* v, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
+                                 double* u, double* v, void* ws, size_t ws_bytes, void* stream) {
   using namespace nif;
   if (!C || !col4row || n <= 0 || ldc < n) return NIF_ERR_INVALID_ARG;
   if (n > NIF_LAP_MAX_N) return NIF_ERR_UNSUPPORTED;
@@ -296,25 +347,37 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int32_t* co
   int* r4c = row4col ? row4col : reinterpret_cast<int*>(b + w.off_r4c);
 
   const int nb = (n + 255) / 256;
+  const bool scipy_order = (flags & NIF_LAP_SCIPY_ORDER) != 0;
+  if (scipy_order) {
+    hipLaunchKernelGGL(lap_zero_init_kernel, dim3(nb), dim3(256), 0, st, n, uu, vv, col4row, r4c);
+  } else {
   hipLaunchKernelGGL(lap_colmin_partial_kernel, dim3(nb, w.chunks), dim3(256), 0, st, C, ldc, n, w.rows_per_chunk,
                      part);
   hipLaunchKernelGGL(lap_colmin_final_kernel, dim3(nb), dim3(256), 0, st, part, w.chunks, n, vv, claim);
   hipLaunchKernelGGL(lap_rowmin_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, ldc, n, vv, uu, jbest, claim);
   hipLaunchKernelGGL(lap_greedy_finish_kernel, dim3(nb), dim3(256), 0, st, n, jbest, claim, col4row, r4c);
+  }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
 
   int cpt = 1;
   while (cpt < 8 && (n + cpt - 1) / cpt > 1024) cpt *= 2;
   int threads = ((n + cpt - 1) / cpt + 63) / 64 * 64;
   if (threads > 1024) return NIF_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)((3 * n + 3) & ~3) * sizeof(int) + 32 * sizeof(double) + 64 * sizeof(int);
+  const size_t lds =
+      (size_t)(((scipy_order ? 4 : 3) * n + 3) & ~3) * sizeof(int) + 32 * sizeof(double) + 96 * sizeof(int);
   prof_begin(NIF_PROF_LAP, st);
+#define NIF_LAP_GO(CPT)                                                                       \
+  do {                                                                                        \
+    if (scipy_order) launch_augment<CPT, true>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); \
+    else launch_augment<CPT, false>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c);       \
+  } while (0)
   switch (cpt) {
-    case 1: launch_augment<1>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); break;
-    case 2: launch_augment<2>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); break;
-    case 4: launch_augment<4>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); break;
-    default: launch_augment<8>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); break;
+    case 1: NIF_LAP_GO(1); break;
+    case 2: NIF_LAP_GO(2); break;
+    case 4: NIF_LAP_GO(4); break;
+    default: NIF_LAP_GO(8); break;
   }
+#undef NIF_LAP_GO
   prof_end(NIF_PROF_LAP, st);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }

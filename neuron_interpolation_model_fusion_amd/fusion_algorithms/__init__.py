@@ -1,0 +1,2 @@
+from .git_rebasin import GitRebasin  # noqa: F401
+from .otfusion import OTFusion  # noqa: F401

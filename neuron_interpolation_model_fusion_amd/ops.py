@@ -103,11 +103,13 @@ def cost_hf(G01, pp0, pp1, r0, r1, s0, s1):
     return C
 
 
-def lap_solve(C, duals=False):
+def lap_solve(C, duals=False, scipy_order=False):
     """Min-cost perfect matching of a square f32 cost matrix on the device.
 
     Returns col4row (int32, device) -- scipy's ``col_ind`` -- and, with duals=True,
-    also (row4col, u, v).
+    also (row4col, u, v).  scipy_order=True replays scipy's augmentation order and tie rule
+    (NIF_LAP_SCIPY_ORDER): same matching as scipy.optimize.linear_sum_assignment even when the
+    optimum is not unique because of exact structural ties; slower.
     """
     _need_gpu(C)
     C = _mat(C, 'C')
@@ -123,7 +125,7 @@ def lap_solve(C, duals=False):
         v = torch.empty(n, dtype=torch.float64, device=C.device) if duals else None
         nbytes = lib.nif_lap_workspace_bytes(n)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=C.device)
-        check(lib.nif_lap_solve_f32(_ptr(C), _ld(C), n, _ptr(col), _ptr(row), _ptr(u), _ptr(v), _ptr(ws), nbytes,
+        check(lib.nif_lap_solve_f32(_ptr(C), _ld(C), n, _lib.NIF_LAP_SCIPY_ORDER if scipy_order else 0, _ptr(col), _ptr(row), _ptr(u), _ptr(v), _ptr(ws), nbytes,
                                     _stream()), 'nif_lap_solve_f32')
     if duals:
         return col, row, u, v

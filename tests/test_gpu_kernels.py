@@ -127,9 +127,9 @@ def test_cost_dist_and_hf(ops):
     assert torch.allclose(Ch.double(), ref_h, rtol=1e-5)
 
 
-def _check_lap(ops, C):
+def _check_lap(ops, C, scipy_order=False):
     n = C.shape[0]
-    col, row, u, v = ops.lap_solve(C.cuda(), duals=True)
+    col, row, u, v = ops.lap_solve(C.cuda(), duals=True, scipy_order=scipy_order)
     col = col.cpu().numpy().astype(np.int64)
     row = row.cpu().numpy()
     assert sorted(col.tolist()) == list(range(n)), 'not a permutation'
@@ -172,3 +172,23 @@ def test_lap_planted_and_ties(ops):
     _check_lap(ops, torch.zeros(50, 50))
     # negative costs
     _check_lap(ops, torch.randn(300, 300, generator=g))
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 33, 64, 200, 384, 1025, 2100])
+def test_lap_scipy_order_reproduces_scipy_under_ties(ops, n):
+    """Structural ties (duplicated rows / columns, constant blocks, small integers): the scipy-order
+    mode must return scipy's own col_ind, not just an optimal one."""
+    g = torch.Generator().manual_seed(100 + n)
+    cases = [torch.zeros(n, n), torch.randint(0, 3, (n, n), generator=g).float()]
+    C = torch.rand(n, n, generator=g)
+    if n >= 5:
+        dead_c = torch.randperm(n, generator=g)[: max(2, n // 4)]
+        dead_r = torch.randperm(n, generator=g)[: max(2, n // 5)]
+        C2 = C.clone()
+        C2[:, dead_c] = C2[:, dead_c[:1]]   # identical columns (dead units of model 1)
+        C2[dead_r, :] = C2[dead_r[:1], :]   # identical rows (dead units of model 0)
+        cases.append(C2)
+    cases.append(C)
+    for Cx in cases:
+        col, ref = _check_lap(ops, Cx, scipy_order=True)
+        assert (col == ref).all()
