@@ -157,6 +157,50 @@ int nif_refit_gather(const float* W0, const float* W1, const int32_t* rowsrc, co
                      const float* alpha_v, const float* beta_v, float alpha, float beta, int n_out,
                      int n_in, int sp, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Neuron k-means in Gram form.  G (N x N f64, ldg) holds the inner products of the neuron
+ * vectors that form centroids, nn[j] the squared norm of the neuron vector that distances
+ * are measured to (KF: G = (XW)^T (XW) and nn = |a_j|^2, hf_kf.py:425-441,454-456;
+ * ALF: G = A^T A and nn = diag(G), alf.py:227,242-244).  s = importance weights (f32, N).
+ * Labels are int32.  ws from nif_kmeans_workspace_bytes(N, k).
+ * ------------------------------------------------------------------------- */
+size_t nif_kmeans_workspace_bytes(int N, int k);
+
+/* KF farthest-point initialisation, hf_kf.py:424-441: picks[0] = first, then k-1 times the
+ * neuron farthest from its nearest chosen centroid (centroid = projected neuron, distance to
+ * the raw neuron); assign = nearest of the k centroids (lowest on ties).  mind: N f64 scratch.
+ * One workgroup; replaces k full k x N x m cdist calls by k reads of one Gram row. */
+int nif_kmeans_farthest_init(const double* G, int64_t ldg, const double* nn, int N, int k, int first,
+                             int32_t* picks, int32_t* assign, double* mind, void* stream);
+
+/* ALF initial assignment, alf.py:221-229: centroids are neurons c0 .. c0+k-1. */
+int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn, int N, int k, int c0,
+                                 int32_t* assign, void* stream);
+
+/* One Lloyd step, hf_kf.py:454-459 / alf.py:242-245: importance-weighted centroids of the
+ * NON-EMPTY clusters of `assign` (compacted in label order, hf_kf.py:294-296, alf.py:155-157),
+ * nearest centroid of every neuron -> assign_out (compact labels), nearest (distance, f64),
+ * *cost = sum_j s_j * nearest_j, *kprime = number of non-empty clusters (device scalars). */
+int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double* nn, const float* s,
+                          const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
+                          double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream);
+
+/* KF empty-cluster repair, hf_kf.py:466-471, in place; *changed = (assign != prev).any(). */
+int nif_kmeans_repair_kf(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N,
+                         int k, int32_t* changed, void* ws, size_t ws_bytes, void* stream);
+
+/* Fused neurons from a clustering, hf_kf.py:283-312,494-504: out[cc][r] = sum_{i in c} s_i W[r][i] / S_c
+ * for the non-empty clusters in label order (rows >= *kprime stay zero). W: d x N f64 (LS solutions
+ * as columns), out: k x d f32. */
+int nif_kmeans_centroid_weights(const double* W, int64_t ldw, const float* s, const int32_t* assign, int N,
+                                int k, int d, float* out, int32_t* kprime, void* ws, size_t ws_bytes,
+                                void* stream);
+
+/* HF fused neurons, hf_kf.py:261-275: out[i][r] = a_i W[r][i] + b_i W[r][n0 + col[i]] with
+ * a_i = s0_i / (s0_i + s1_col[i]), b_i = 1 - a_i.  W: d x (n0 + n1) f64, out: n0 x d f32. */
+int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const float* s0, const float* s1,
+                    int n0, int d, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

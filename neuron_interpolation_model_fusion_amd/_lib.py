@@ -36,6 +36,13 @@ SIGNATURES = {
     'nif_cost_hf': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'nif_lap_workspace_bytes': (_sz, [_i32]),
     'nif_lap_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nif_kmeans_workspace_bytes': (_sz, [_i32, _i32]),
+    'nif_kmeans_farthest_init': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'nif_kmeans_assign_to_neurons': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'nif_kmeans_lloyd_step': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nif_kmeans_repair_kf': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    'nif_kmeans_centroid_weights': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'nif_refit_pairs': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     'nif_refit_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32, _vp, _vp]),
 }
 

@@ -1,0 +1,232 @@
+"""HF / KF linear fusion on MI355X (reference: fusion_algorithms/hf_kf.py).
+
+Same class, attributes and ``fuse`` signature.  What changed underneath, per layer:
+
+* LS refit (hf_kf.py:213,233-234 / 377,397: ``torch.linalg.pinv(X) @ acts``): normal equations
+  built with the f64 MFMA Gram kernel and solved through an eigendecomposition truncated at
+  pinv's own cutoff (ops.ls_solve) -- X is never inverted and never leaves the device.
+* HF cost (hf_kf.py:93-124: n0*n1/64 chunked (m x d) @ (d x 64) matmuls): closed form on the
+  PROJECTED activations.  With P = X pinv(X), p = P a:  pred - a0_i = b (p1_j - p0_i)
+  - (a0_i - p0_i), the two parts orthogonal, so C_ij = s0_i sqrt(b^2 D_ij + r0_i) + s1_j sqrt(a^2
+  D_ij + r1_j) with D = ||p0_i - p1_j||^2 and r the squared LS residuals.  All of it comes from
+  R = X^T A and W: P0^T P1 = R0^T W1 (a d-contraction), ||p_i||^2 = <R_i, W_i>, r = ||a||^2 - ||p||^2.
+* assignment (hf_kf.py:251): device LAP kernel in scipy order (identical matching under ties).
+* KF k-means (hf_kf.py:405-490): Gram form on G = R^T W, every step one pass over that N x N
+  matrix (ops.KMeans); the farthest-point initialisation reads one Gram row per step instead of
+  recomputing a c x N x m cdist.
+"""
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.fusion_utils import (
+    get_num_layers, initialize_activations, get_layer_width, compute_neuron_importance_scores)
+from ..utils.model_utils import is_conv_weight
+
+COST_MATRIX_VECTORIZED_CHUNK_SIZE = 8  # kept for source compatibility (hf_kf.py:19); unused by the closed form
+
+
+class LSFusion:
+    fusion_methods = ['hungarian', 'k_means']
+    neuron_importance_methods = ['uniform', 'conductance', 'deeplift', 'featureablation']
+
+    def __init__(self, models):
+        self.models = models
+        self.neuron_importance_scores = None
+        self.last_layer_info = []  # per layer of the last fuse(): dict(cost, col) or dict(assign)
+
+    @property
+    def device(self):
+        return self.models[0].device
+
+    def _config_check(self, fusion_method, neuron_importance_method):
+        if fusion_method not in self.fusion_methods:
+            raise ValueError(f'Invalid fusion importance method: {fusion_method}')
+        if neuron_importance_method not in self.neuron_importance_methods:
+            raise ValueError(f'Invalid neuron importance method: {neuron_importance_method}')
+
+    # -- shared per-layer set-up --------------------------------------------------------------------
+    @staticmethod
+    def _design_matrix(fused_hat, layer_idx):
+        """Layer input as (m, d): im2col rows for conv, ones column for the bias
+        (hf_kf.py:196-208); row stride padded for 16-byte loads."""
+        rep = fused_hat.get_ordered_trainable_named_layers[layer_idx]
+        X = fused_hat.get_inputs_and_preactivations(layer_idx)[0]
+        in_filters = None
+        if is_conv_weight(rep.weight):
+            conv = rep.layer
+            in_filters = conv.in_channels
+            X = F.unfold(X, kernel_size=conv.kernel_size, stride=conv.stride, padding=conv.padding)
+            X = X.permute(0, 2, 1).reshape(-1, in_filters * int(np.prod(conv.kernel_size)))
+        else:
+            X = X.reshape(X.shape[0], -1)
+        use_bias = rep.layer.bias is not None
+        d = X.shape[1] + (1 if use_bias else 0)
+        Xp = ops.padded_rows(X.shape[0], d, X.device)
+        Xp[:, :X.shape[1]] = X
+        if use_bias:
+            Xp[:, -1] = 1.0
+        return Xp, in_filters, use_bias
+
+    def _layer_acts(self, models, layer_idx, rows, is_conv):
+        acts = torch.cat(tuple(m.get_inputs_and_preactivations(layer_idx)[1] for m in models), dim=1)
+        if is_conv:
+            acts = acts.permute(0, 2, 3, 1).reshape(rows, -1)
+        return acts.contiguous()
+
+    @staticmethod
+    def _split_rows(rows, fused_hat, layer_idx, use_bias, is_conv, in_filters):
+        """(n, d) fused neurons -> (new_weight, new_bias) in the layer's own shapes (hf_kf.py:266-279);
+        the bias lives on the CPU like the reference's (:260,402)."""
+        n = rows.shape[0]
+        new_bias = None
+        if use_bias:
+            new_bias = rows[:, -1].clone().cpu()
+            rows = rows[:, :-1]
+        new_weight = rows.reshape(n, in_filters, -1) if is_conv else rows
+        return new_weight.contiguous(), new_bias
+
+    @staticmethod
+    def _get_cost_matrix_vectorized_chunked(X, acts0, acts1, w0, w1, s0, s1, chunk_size=COST_MATRIX_VECTORIZED_CHUNK_SIZE):
+        """HF cost matrix for given LS solutions w0 (d, n0), w1 (d, n1); same arguments and numpy
+        result as the reference's static method (hf_kf.py:93-124), closed form on the device."""
+        R, _, na = ops.xty(X, torch.cat([acts0, acts1], dim=1).contiguous(), acc='f64')
+        W = torch.cat([w0, w1], dim=1).double().contiguous()
+        n0 = w0.shape[1]
+        G01, _, _ = ops.xty(R[:, :n0], W[:, n0:], acc='f64', norms=False)
+        pp = (R * W).sum(0)
+        r = (na - pp).clamp_min(0)
+        return ops.cost_hf(G01, pp[:n0], pp[n0:], r[:n0], r[n0:], s0, s1).cpu().numpy()
+
+    # -- HF ---------------------------------------------------------------------------------------------
+    def _fuse_layer_hungarian(self, layer_idx, fused_hat, norm_acts):
+        """hf_kf.py:186-281."""
+        layers = fused_hat.get_ordered_trainable_named_layers
+        is_conv = is_conv_weight(layers[layer_idx].weight)
+        X, in_filters, use_bias = self._design_matrix(fused_hat, layer_idx)
+        dev = X.device
+        start = time.time()
+        acts = self._layer_acts(self.models[:2], layer_idx, X.shape[0], is_conv)
+        sol = ops.ls_solve(X, acts, normalize=norm_acts)
+        print(f'Pseudo-inverse time: {time.time() - start}')
+        s0 = self.neuron_importance_scores[0][layer_idx].clone().to(dev)
+        s1 = self.neuron_importance_scores[1][layer_idx].clone().to(dev)
+        n0 = get_layer_width(self.models[0], layer_idx)
+        W, R, na = sol['W'], sol['R'], sol['na']
+
+        start = time.time()
+        G01, _, _ = ops.xty(R[:, :n0], W[:, n0:], acc='f64', norms=False)  # P0^T P1
+        pp = (R * W).sum(0)                                                  # ||p_i||^2
+        r = (na - pp).clamp_min(0)                                           # squared LS residuals
+        cost = ops.cost_hf(G01, pp[:n0], pp[n0:], r[:n0], r[n0:], s0, s1)
+        print(f'Cost matrix time: {time.time() - start}')
+        print()
+        col = ops.lap_solve(cost, scipy_order=True)
+        self.last_layer_info.append(dict(cost=cost, col=col, W=W))
+        if layer_idx == len(layers) - 1:
+            col = torch.arange(n0, device=dev, dtype=torch.int32)  # identity on the output layer (:254-255)
+        rows = ops.refit_pairs(W, col, s0, s1, n0)
+        return self._split_rows(rows, fused_hat, layer_idx, use_bias, is_conv, in_filters)
+
+    # -- KF ---------------------------------------------------------------------------------------------
+    def _fuse_layer_k_means(self, layer, fused_hat, norm_acts, num_k_means_tries=10,
+                            k_means_early_stop_minimum_improvement=0.05, k_means_early_stop_steps_check=3):
+        """hf_kf.py:345-510."""
+        layers = fused_hat.get_ordered_trainable_named_layers
+        is_conv = is_conv_weight(layers[layer].weight)
+        is_last_layer = layer == len(layers) - 1
+        output_size = layers[layer].weight.shape[0]
+        X, in_filters, use_bias = self._design_matrix(fused_hat, layer)
+        dev = X.device
+        start = time.time()
+        acts = self._layer_acts(self.models, layer, X.shape[0], is_conv)
+        sol = ops.ls_solve(X, acts, normalize=norm_acts)
+        print(f'Pseudo-inverse time: {time.time() - start}')
+        s = torch.cat([self.neuron_importance_scores[k][layer].clone() for k in range(len(self.models))], dim=0).to(dev)
+        W, R, na = sol['W'], sol['R'], sol['na']
+
+        identity = torch.cat([torch.arange(output_size, dtype=torch.int32) for _ in self.models]).to(dev)
+        if is_last_layer:
+            km = ops.KMeans(None, na, s, output_size)  # grouping only: one cluster per output unit (:405-406)
+            best_assignment = identity
+        else:
+            GP, _, _ = ops.xty(R, W, acc='f64', norms=False)  # (XW)^T (XW) = R^T W
+            km = ops.KMeans(GP, na, s, output_size)
+            best_assignment, best_total_cost = identity, np.inf
+            start = time.time()
+            t_init = t_conv = 0.0
+            it_init = it_conv = 0
+            for _ in range(num_k_means_tries):
+                t0 = time.time()
+                first = int(np.random.randint(low=0, high=output_size))  # a neuron of model 0 (:424)
+                _, assignment = km.farthest_init(first)
+                it_init += output_size - 1
+                t_init += time.time() - t0
+                t0 = time.time()
+                costs_log = []
+                changed = True
+                while changed:
+                    it_conv += 1
+                    prev = assignment
+                    assignment, nearest, cost, _ = km.lloyd_step(prev)
+                    current_cost = float(cost.item())
+                    if len(costs_log) >= k_means_early_stop_steps_check and current_cost >= \
+                            costs_log[-k_means_early_stop_steps_check] * (1.0 - k_means_early_stop_minimum_improvement):
+                        print("K-means Early Stopping at ", len(costs_log), " iterations since ", current_cost, " >= ",
+                              costs_log[-k_means_early_stop_steps_check], "*",
+                              (1.0 - k_means_early_stop_minimum_improvement))
+                        break  # before the repair: the un-repaired assignment is kept (:460-462)
+                    costs_log.append(current_cost)
+                    changed = bool(km.repair_kf(assignment, nearest, prev).item())
+                _, _, total, _ = km.lloyd_step(assignment)
+                total_cost = float(total.item())
+                if total_cost < best_total_cost:
+                    best_assignment, best_total_cost = assignment, total_cost
+                t_conv += time.time() - t0
+            print(f'K-means time: {(time.time() - start):.2f}, Centroid Initialization Time: {t_init:.2f}, '
+                  f'Centroid Initialization Iterations: {it_init}, Centroid Convergence Time: {t_conv:.2f}, '
+                  f'Centroid Convergence Iterations: {it_conv}')
+        print()
+        self.last_layer_info.append(dict(assign=best_assignment, W=W))
+        rows, _ = km.centroid_weights(W, best_assignment)
+        return self._split_rows(rows, fused_hat, layer, use_bias, is_conv, in_filters)
+
+    def fuse(self, activation_dataset, activation_labels, fusion_method='hungarian', neuron_importance_method='uniform',
+             norm_acts=False, norm_neuron_importance=True):
+        """hf_kf.py:512-569."""
+        self._config_check(fusion_method, neuron_importance_method)
+        num_layers = get_num_layers(self.models)
+        start_time = time.time()
+        self.neuron_importance_scores = [[] for _ in range(len(self.models))]
+        for k, model in enumerate(self.models):
+            for layer_idx in range(num_layers):
+                scores = compute_neuron_importance_scores(neuron_importance_method, model, layer_idx,
+                                                          activation_dataset, activation_labels, fusion_logic='layer')
+                if norm_neuron_importance:
+                    scores = scores / torch.sum(scores)
+                self.neuron_importance_scores[k].append(scores)
+        print(f'Neuron Importance Score Time: {time.time() - start_time}')
+
+        for m in self.models:
+            m.to(activation_dataset.device)
+            initialize_activations(m, activation_dataset)
+        fused_hat = self.models[0].copy_model().eval()
+        self.last_layer_info = []
+        for layer_idx in range(num_layers):
+            print(f'Fusing layer {layer_idx + 1}/{num_layers}')
+            initialize_activations(fused_hat, activation_dataset)  # the fused model's input changes every layer
+            if fusion_method == 'hungarian':
+                new_W, new_b = self._fuse_layer_hungarian(layer_idx, fused_hat, norm_acts)
+            else:
+                new_W, new_b = self._fuse_layer_k_means(layer_idx, fused_hat, norm_acts)
+            fused_hat.set_weight_at_layer(layer_idx, new_W)
+            if new_b is not None:
+                fused_hat.set_bias_at_layer(layer_idx, new_b)
+
+        for m in self.models:
+            m.remove_hooks()
+        fused_hat.remove_hooks()
+        return fused_hat.copy_model()

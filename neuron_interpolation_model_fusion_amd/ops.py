@@ -171,3 +171,144 @@ def profile_collect(slot):
     ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
     check(lib.nif_profile_collect(slot, ctypes.byref(ms), ctypes.byref(cnt)), 'nif_profile_collect')
     return ms.value, cnt.value
+
+
+# ---- least-squares refit (hf_kf.py:213,233-234,377,397) ---------------------------------------------
+
+_EPS32 = 1.1920928955078125e-07
+
+
+def padded_rows(m, d, device, dtype=torch.float32):
+    """(m, d) view of a zero buffer whose row stride is a multiple of 4 elements, so the Gram kernel can
+    use 16-byte loads on design matrices of odd width (d = fan_in + 1)."""
+    ld = (d + 3) // 4 * 4
+    return torch.zeros((m, ld), dtype=dtype, device=device)[:, :d]
+
+
+def ls_solve(X, A, normalize=False):
+    """Minimum-norm least squares W = pinv(X) @ A with torch.linalg.pinv's cutoff for f32 inputs
+    (singular values <= max(m, d) * eps_f32 * sigma_max are dropped), from normal equations:
+
+      m >= d:  G = X^T X, R = X^T A (f64 MFMA);  G = V L V^T;  W = V L_kept^-1 V^T R
+      m <  d:  K = X X^T;  K = U L U^T;  W = X^T (U L_kept^-1 U^T A)          (dual form)
+
+    The Gram build and every dense product run on nif_xty; the symmetric eigendecomposition is
+    torch.linalg.eigh on the device for now (interim library call -- see DESIGN.md).
+    normalize=True scales A's columns to unit norm first (fusion_utils.py:38-40).
+    Returns dict(W (d x N f64), R = X^T A (d x N f64), na = squared column norms of A (N f64), rank).
+    """
+    _need_gpu(X, A)
+    m, d = X.shape
+    R, _, na = xty(X, A, acc='f64')
+    if normalize:
+        inv = 1.0 / na.sqrt()
+        R = R * inv[None, :]
+        na = torch.ones_like(na)
+    rtol = max(m, d) * _EPS32
+    if m >= d:
+        G, _, _ = xty(X, None, acc='f64', norms=False)
+        lam, V = torch.linalg.eigh(G)
+        keep = lam > (rtol * rtol) * lam[-1]
+        inv_lam = torch.where(keep, 1.0 / lam, torch.zeros_like(lam))
+        Z, _, _ = xty(V, R, acc='f64', norms=False)          # V^T R
+        Z = Z * inv_lam[:, None]
+        W, _, _ = xty(V, Z, acc='f64', trans_a=True, norms=False)   # V Z
+    else:
+        K, _, _ = xty(X, None, acc='f64', trans_a=True, norms=False)  # X X^T
+        lam, U = torch.linalg.eigh(K)
+        keep = lam > (rtol * rtol) * lam[-1]
+        inv_lam = torch.where(keep, 1.0 / lam, torch.zeros_like(lam))
+        A64 = A.double()
+        if normalize:
+            A64 = A64 * inv[None, :]
+        Z, _, _ = xty(U, A64, acc='f64', norms=False)        # U^T A
+        Z = Z * inv_lam[:, None]
+        Y, _, _ = xty(U, Z, acc='f64', trans_a=True, norms=False)   # U Z  (m x N)
+        W, _, _ = xty(X.double(), Y, acc='f64', norms=False)        # X^T Y
+    return dict(W=W, R=R, na=na, rank=int(keep.sum().item()))
+
+
+def refit_pairs(W, col, s0, s1, n0):
+    """HF fused neurons: out[i] = a_i W[:, i] + b_i W[:, n0 + col[i]] as rows (n0 x d f32)."""
+    _need_gpu(W, col)
+    d = W.shape[0]
+    dev = W.device
+    col = col.to(device=dev, dtype=torch.int32).contiguous()
+    s0 = s0.to(device=dev, dtype=torch.float32).contiguous()
+    s1 = s1.to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        out = torch.empty((n0, d), dtype=torch.float32, device=dev)
+        check(lib.nif_refit_pairs(_ptr(W), W.stride(0), _ptr(col), _ptr(s0), _ptr(s1), n0, d, _ptr(out), _stream()),
+              'nif_refit_pairs')
+    return out
+
+
+# ---- Gram-form k-means --------------------------------------------------------------------------------
+
+class KMeans:
+    """Device state of one Gram-form k-means problem (see nif_kmeans_* in include/nif.h)."""
+
+    def __init__(self, G, nn, s, k):
+        _need_gpu(G, nn)
+        self.G = None if G is None else G.contiguous()  # None: only centroid_weights() may be used
+        self.dev = nn.device
+        self.N = nn.shape[0]
+        self.k = int(k)
+        self.nn = nn.to(device=self.dev, dtype=torch.float64).contiguous()
+        self.s = s.to(device=self.dev, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.dev):
+            self.nbytes = lib.nif_kmeans_workspace_bytes(self.N, self.k)
+            self.ws = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=self.dev)
+            self.mind = torch.empty(self.N, dtype=torch.float64, device=self.dev)
+
+    def _i32(self, n):
+        return torch.empty(n, dtype=torch.int32, device=self.dev)
+
+    def farthest_init(self, first):
+        """(picks, assign) of the KF farthest-point initialisation started at neuron `first`."""
+        with torch.cuda.device(self.dev):
+            picks, assign = self._i32(self.k), self._i32(self.N)
+            check(lib.nif_kmeans_farthest_init(_ptr(self.G), self.G.stride(0), _ptr(self.nn), self.N, self.k,
+                                               int(first), _ptr(picks), _ptr(assign), _ptr(self.mind), _stream()),
+                  'nif_kmeans_farthest_init')
+        return picks, assign
+
+    def assign_to_neurons(self, c0):
+        with torch.cuda.device(self.dev):
+            assign = self._i32(self.N)
+            check(lib.nif_kmeans_assign_to_neurons(_ptr(self.G), self.G.stride(0), _ptr(self.nn), self.N, self.k,
+                                                   int(c0), _ptr(assign), _stream()), 'nif_kmeans_assign_to_neurons')
+        return assign
+
+    def lloyd_step(self, assign):
+        """(assign_out, nearest, cost, kprime): cost / kprime are 0-d device tensors."""
+        with torch.cuda.device(self.dev):
+            out = self._i32(self.N)
+            nearest = torch.empty(self.N, dtype=torch.float64, device=self.dev)
+            cost = torch.empty((), dtype=torch.float64, device=self.dev)
+            kprime = torch.empty((), dtype=torch.int32, device=self.dev)
+            check(lib.nif_kmeans_lloyd_step(_ptr(self.G), self.G.stride(0), _ptr(self.nn), _ptr(self.s), _ptr(assign),
+                                            self.N, self.k, _ptr(out), _ptr(nearest), _ptr(cost), _ptr(kprime),
+                                            _ptr(self.ws), self.nbytes, _stream()), 'nif_kmeans_lloyd_step')
+        return out, nearest, cost, kprime
+
+    def repair_kf(self, assign, nearest, prev):
+        """In-place KF empty-cluster repair; returns the 0-d device flag (assign != prev).any()."""
+        with torch.cuda.device(self.dev):
+            changed = torch.empty((), dtype=torch.int32, device=self.dev)
+            check(lib.nif_kmeans_repair_kf(_ptr(assign), _ptr(nearest), _ptr(self.s), _ptr(prev), self.N, self.k,
+                                           _ptr(changed), _ptr(self.ws), self.nbytes, _stream()),
+                  'nif_kmeans_repair_kf')
+        return changed
+
+    def centroid_weights(self, W, assign):
+        """k x d f32 rows: importance-weighted mean of the member columns of W (d x N f64) per
+        non-empty cluster in label order; trailing rows zero.  Returns (rows, kprime)."""
+        d = W.shape[0]
+        with torch.cuda.device(self.dev):
+            out = torch.empty((self.k, d), dtype=torch.float32, device=self.dev)
+            kprime = torch.empty((), dtype=torch.int32, device=self.dev)
+            check(lib.nif_kmeans_centroid_weights(_ptr(W), W.stride(0), _ptr(self.s), _ptr(assign), self.N, self.k, d,
+                                                  _ptr(out), _ptr(kprime), _ptr(self.ws), self.nbytes, _stream()),
+                  'nif_kmeans_centroid_weights')
+        return out, kprime

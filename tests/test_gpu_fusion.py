@@ -64,3 +64,46 @@ def test_otfusion_normalized_acts(dev):
     fused = OTFusion(models[:1], models[1]).fuse_models(strategy)
     ref = o_otf.otf_fuse(cpu_models[:1], cpu_models[1], Xc, mode='acts', normalize=True)
     assert_state_close(fused, dict(ref.state_dict()), rtol=1e-3)
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_hf_matches_reference_golden(dev, name):
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import LSFusion
+    z = load_npz(name)
+    models, X = build_models(name, z, dev)
+    ls = LSFusion(models[:2])
+    fused = ls.fuse(X, None, fusion_method='hungarian', neuron_importance_method='uniform')
+    n_layers = len(ls.last_layer_info)
+    for l, info in enumerate(ls.last_layer_info):
+        ref = z[f'hf.cost{l}']
+        np.testing.assert_allclose(info['cost'].cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * ref.max())
+        if f'hf.w0_{l}' in z.files:
+            wref = np.concatenate([z[f'hf.w0_{l}'], z[f'hf.w1_{l}']], axis=1)
+            w = info['W'].cpu().numpy()
+            assert np.abs(w - wref).max() <= 2e-3 * np.abs(wref).max(), f'LS solution, layer {l}'
+        assert (info['col'].cpu().numpy() == z[f'hf.col{l}']).all(), f'layer {l}'
+    assert_state_close(fused, fused_state(z, 'hf'), rtol=1e-3)
+
+
+def test_hf_norm_acts_matches_reference_golden(dev):
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import LSFusion
+    z = load_npz('mlp_small')
+    models, X = build_models('mlp_small', z, dev)
+    ls = LSFusion(models[:2])
+    fused = ls.fuse(X, None, fusion_method='hungarian', neuron_importance_method='uniform', norm_acts=True)
+    for l, info in enumerate(ls.last_layer_info):
+        assert (info['col'].cpu().numpy() == z[f'hfn.col{l}']).all(), f'layer {l}'
+    assert_state_close(fused, fused_state(z, 'hfn'), rtol=1e-3)
+
+
+@pytest.mark.parametrize('name,count', [('mlp_small', 2), ('mlp_small', 4), ('mlp_wide', 3), ('vgg_tiny', 3)])
+def test_kf_matches_reference_golden(dev, name, count):
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import LSFusion
+    z = load_npz(name)
+    models, X = build_models(name, z, dev)
+    np.random.seed(int(z['meta.seed'][0]))
+    ls = LSFusion(models[:count])
+    fused = ls.fuse(X, None, fusion_method='k_means', neuron_importance_method='uniform')
+    for l, info in enumerate(ls.last_layer_info):
+        assert (info['assign'].cpu().numpy() == z[f'kf{count}.assign{l}']).all(), f'layer {l}'
+    assert_state_close(fused, fused_state(z, f'kf{count}'), rtol=1e-3)
