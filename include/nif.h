@@ -196,6 +196,12 @@ int nif_kmeans_centroid_weights(const double* W, int64_t ldw, const float* s, co
                                 int k, int d, float* out, int32_t* kprime, void* ws, size_t ws_bytes,
                                 void* stream);
 
+/* ALF level targets, alf.py:288-289 (with _calculate_centroids :145-169): T[r][cc] = weighted mean
+ * over the member neurons of cluster c of A[r][.], for every sample row; A: m x N f32 (the
+ * un-normalised level outputs of all models side by side), T: m x k f32, columns >= *kprime zero. */
+int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const float* w, const int32_t* assign, int N,
+                       int k, float* T, int64_t ldt, int32_t* kprime, void* ws, size_t ws_bytes, void* stream);
+
 /* HF fused neurons, hf_kf.py:261-275: out[i][r] = a_i W[r][i] + b_i W[r][n0 + col[i]] with
  * a_i = s0_i / (s0_i + s1_col[i]), b_i = 1 - a_i.  W: d x (n0 + n1) f64, out: n0 x d f32. */
 int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const float* s0, const float* s1,

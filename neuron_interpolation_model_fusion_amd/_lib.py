@@ -42,6 +42,7 @@ SIGNATURES = {
     'nif_kmeans_lloyd_step': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nif_kmeans_repair_kf': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     'nif_kmeans_centroid_weights': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'nif_kmeans_targets': (_i32, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     'nif_refit_pairs': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     'nif_refit_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32, _vp, _vp]),
 }

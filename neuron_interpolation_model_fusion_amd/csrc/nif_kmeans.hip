@@ -302,6 +302,31 @@ __global__ void kmeans_centroid_weights_kernel(const double* __restrict__ W, int
   out[(int64_t)cc * d + r] = (float)(acc / tot);
 }
 
+// ALF targets (alf.py:288-289): T[r][cc] = sum_{i in c} w_i A[r][i] / S_c for every sample row r --
+// the importance-weighted centroid of the member neurons' (un-normalised) activations.
+// One thread per (row, cluster); lanes walk consecutive clusters of one row, whose members all
+// lie inside that row's N floats (served from L1/L2 after the first touch), and write T coalesced.
+__global__ void kmeans_targets_kernel(const float* __restrict__ A, int64_t lda, int64_t m, const float* __restrict__ w,
+                                      const int* __restrict__ order, const int* __restrict__ seg,
+                                      const int* __restrict__ compact, int k, float* __restrict__ T, int64_t ldt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  const int cc = compact[c];
+  const int b = seg[c], e = seg[c + 1];
+  double tot = 0.0;
+  for (int t = b; t < e; ++t) tot += (double)w[order[t]];
+  for (int64_t r = blockIdx.y; r < m; r += gridDim.y) {
+    if (cc < 0) continue;
+    const float* __restrict__ row = A + r * lda;
+    double acc = 0.0;
+    for (int t = b; t < e; ++t) {
+      const int i = order[t];
+      acc += (double)w[i] * (double)row[i];
+    }
+    T[r * ldt + cc] = (float)(acc / tot);
+  }
+}
+
 struct KmWs {
   size_t off_rank, off_counts, off_seg, off_compact, off_order, off_H, off_S, off_cn, off_partial, total;
   int nblk;
@@ -424,5 +449,26 @@ extern "C" int nif_kmeans_centroid_weights(const double* W, int64_t ldw, const f
   hipLaunchKernelGGL(kmeans_centroid_weights_kernel, dim3((d + 255) / 256, k), dim3(256), 0, st, W, ldw, s,
                      reinterpret_cast<int*>(b + w.off_order), reinterpret_cast<int*>(b + w.off_seg),
                      reinterpret_cast<int*>(b + w.off_compact), d, out);
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+}
+
+extern "C" int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const float* w, const int32_t* assign, int N,
+                                  int k, float* T, int64_t ldt, int32_t* kprime, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  using namespace nif;
+  if (!A || !w || !assign || !T || !kprime || m <= 0 || N <= 0 || k <= 0 || lda < N || ldt < k)
+    return NIF_ERR_INVALID_ARG;
+  const KmWs ww = km_ws(N, k);
+  if (!ws || ws_bytes < ww.total) return NIF_ERR_WORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  clear_err();
+  unsigned char* b = reinterpret_cast<unsigned char*>(ws);
+  km_group(assign, N, k, ww, b, kprime, st);
+  (void)hipMemset2DAsync(T, (size_t)ldt * sizeof(float), 0, (size_t)k * sizeof(float), (size_t)m, st);
+  const int threads = k >= 256 ? 256 : (k + 63) / 64 * 64;
+  int64_t gy = m < 16384 ? m : 16384;
+  hipLaunchKernelGGL(kmeans_targets_kernel, dim3((k + threads - 1) / threads, (unsigned)gy), dim3(threads), 0, st, A,
+                     lda, m, w, reinterpret_cast<int*>(b + ww.off_order), reinterpret_cast<int*>(b + ww.off_seg),
+                     reinterpret_cast<int*>(b + ww.off_compact), k, T, ldt);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }

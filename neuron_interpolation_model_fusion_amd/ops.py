@@ -312,3 +312,16 @@ class KMeans:
                                                   _ptr(out), _ptr(kprime), _ptr(self.ws), self.nbytes, _stream()),
                   'nif_kmeans_centroid_weights')
         return out, kprime
+
+    def targets(self, A, assign):
+        """ALF target matrix (m x k f32): weighted centroid of every cluster's member columns of A
+        (m x N f32), non-empty clusters in label order.  Returns (T, kprime)."""
+        A = _mat(A, 'A')
+        m = A.shape[0]
+        with torch.cuda.device(self.dev):
+            T = torch.empty((m, self.k), dtype=torch.float32, device=self.dev)
+            kprime = torch.empty((), dtype=torch.int32, device=self.dev)
+            check(lib.nif_kmeans_targets(_ptr(A), _ld(A), m, _ptr(self.s), _ptr(assign), self.N, self.k, _ptr(T),
+                                         self.k, _ptr(kprime), _ptr(self.ws), self.nbytes, _stream()),
+                  'nif_kmeans_targets')
+        return T, kprime

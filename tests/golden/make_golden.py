@@ -186,11 +186,13 @@ def run_alf_kmeans(out, models, X, level_idx=0):
             out[f'alf.assign.{tag}'] = assign.numpy().astype(np.int64)
 
 
-def run_alf_fuse(out, models, X, epochs=2):
-    """End-to-end ALFusion.fuse with a short Adam fit (torch RNG seeded)."""
+def run_alf_fuse(out, models, X, epochs=3):
+    """End-to-end ALFusion.fuse with a short plain-SGD fit (torch RNG seeded).  SGD, not Adam: Adam's
+    first steps are lr * sign(gradient), so float noise on near-zero gradients moves a weight by a full
+    lr and a CPU-minted golden could not be compared with a GPU run at a tight tolerance."""
     nlev = len(models[0].get_ordered_trainable_named_levels)
     cfg = ref_alf.ALFusionConfig(
-        X=X, y=None, optimizer_per_level=['adam'] * nlev, lr_per_level=[1e-3] * nlev,
+        X=X, y=None, optimizer_per_level=['sgd'] * nlev, lr_per_level=[5e-2] * nlev,
         weight_decay_per_level=[0.0] * nlev, epochs_per_level=[epochs] * nlev,
         normalize_acts_for_kmeans=True, init_kmeans_with_2nd_acts=False, verbose=False)
     torch.manual_seed(SEED)

@@ -107,3 +107,61 @@ def test_kf_matches_reference_golden(dev, name, count):
     for l, info in enumerate(ls.last_layer_info):
         assert (info['assign'].cpu().numpy() == z[f'kf{count}.assign{l}']).all(), f'layer {l}'
     assert_state_close(fused, fused_state(z, f'kf{count}'), rtol=1e-3)
+
+
+def _alf_config(X, nlev, **kw):
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusionConfig
+    base = dict(X=X, y=None, optimizer_per_level=['adam'] * nlev, lr_per_level=[1e-3] * nlev,
+                weight_decay_per_level=[0.0] * nlev, epochs_per_level=[1] * nlev, verbose=False)
+    base.update(kw)
+    return ALFusionConfig(**base)
+
+
+@pytest.mark.parametrize('name,level', [('mlp_small', 0), ('mlp_wide', 0), ('vgg_tiny', 2)])
+def test_alf_kmeans_matches_reference_golden(dev, name, level):
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusion
+    z = load_npz(name)
+    models, X = build_models(name, z, dev)
+    models = models[:2]
+    alf = ALFusion(models)
+    nlev = len(models[0].get_ordered_trainable_named_levels)
+    alf.ni_scores = [{l: torch.ones(m.get_ordered_trainable_named_levels[l].output_width) for l in range(nlev)}
+                     for m in models]
+    k = models[0].get_ordered_trainable_named_levels[level].output_width
+    for norm in (False, True):
+        for init2 in (False, True):
+            cfg = _alf_config(X, nlev, normalize_acts_for_kmeans=norm, init_kmeans_with_2nd_acts=init2)
+            T, assign = alf._k_means_v2(level, k, cfg, X)
+            tag = f'{int(norm)}{int(init2)}'
+            assert (assign.cpu().numpy() == z[f'alf.assign.{tag}']).all(), tag
+            ref = z[f'alf.T.{tag}']
+            assert T.shape == ref.shape
+            np.testing.assert_allclose(T.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_alf_match_T_to_X_matches_oracle(dev):
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusion
+    from oracle import alf as o_alf
+    g = torch.Generator().manual_seed(4)
+    Xl = torch.randn(300, 40, generator=g)
+    T = Xl[:, torch.randperm(40, generator=g)] + 0.05 * torch.randn(300, 40, generator=g)
+    W = torch.rand(40, generator=g) + 0.5
+    ref, _, _ = o_alf.match_T_to_X(Xl, T, W)
+    got = ALFusion([])._match_T_to_X(Xl.to(dev), T.to(dev), W.to(dev))
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_alf_fuse_end_to_end_matches_reference_golden(dev):
+    """k-means on the HIP path + the reference's own SGD loop (3 epochs) on the GPU; the golden ran
+    the same seeds on the CPU, so only float noise of the training arithmetic separates them."""
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusion
+    z = load_npz('mlp_small')
+    models, X = build_models('mlp_small', z, dev)
+    cfg = _alf_config(X, 2, optimizer_per_level=['sgd'] * 2, lr_per_level=[5e-2] * 2, epochs_per_level=[3, 3],
+                      normalize_acts_for_kmeans=True, init_kmeans_with_2nd_acts=False)
+    copies = [m.copy_model() for m in models[:2]]  # before seeding, like the golden script (construction draws RNG)
+    torch.manual_seed(int(z['meta.seed'][0]))
+    alf = ALFusion(copies)
+    fused = alf.fuse(cfg)
+    assert_state_close(fused, fused_state(z, 'alf'), rtol=1e-3)
+    np.testing.assert_allclose(np.array(alf.weight_change_per_level), z['alf.weight_change'], rtol=1e-2)
