@@ -62,9 +62,8 @@ def level_step(ops, lv, dist=None):
     n = lv['act_k'].shape[1]
     G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32')
     if dist is not None:
-        packed = torch.cat([G.reshape(-1), na, nb])
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-        G, na, nb = packed[:n * n].view(n, n), packed[n * n:n * n + n], packed[n * n + n:]
+        from neuron_interpolation_model_fusion_amd.parallel import allreduce_gram
+        G, na, nb = allreduce_gram(G, na, nb)  # one packed f64 all-reduce per level
     C = ops.cost_dist(G, na, nb)
     col, row, _, _ = ops.lap_solve(C, duals=True)
     # T = P/n, so T^T diag(1/mu) = P^T: target neuron j receives model-k neuron row4col[j]

@@ -109,7 +109,7 @@ class ALFusion:
         """aligned_T[:, r] = T[:, c] for the min-cost matching of cost[i][j] = ||X[:, i] - T[:, j]|| * W[j]."""
         X = self._flatten_acts(X).contiguous()
         T = T.contiguous()
-        G, na, nb = ops.xty(X, T)
+        G, na, nb = ops.xty(X, T, rows_sharded=True)
         cost = ops.cost_dist(G, na, nb, colscale=W)
         col = ops.lap_solve(cost, scipy_order=True)
         aligned = torch.zeros_like(T)
@@ -174,7 +174,7 @@ class ALFusion:
         sw64 = sample_weight.double()
 
         # one symmetric Gram of the clustering vectors; everything below streams it
-        G, _, _ = ops.xty(kmeans_acts, None, acc='f32', norms=False)
+        G, _, _ = ops.xty(kmeans_acts, None, acc='f32', norms=False, rows_sharded=True)
         km = ops.KMeans(G, torch.diagonal(G).contiguous(), sample_weight, target_width)
 
         time_cc, iters = 0.0, 0

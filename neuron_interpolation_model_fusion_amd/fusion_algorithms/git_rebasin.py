@@ -61,7 +61,7 @@ class GitRebasin:
         pre1 = self._rows(self.model1.get_inputs_and_preactivations(layer)[1]).to(device)
         s0 = self.neuron_importance_scores0[layer].to(device)
         s1 = self.neuron_importance_scores1[layer].to(device)
-        G, na, nb = ops.xty(pre0, pre1, relu_a=True, relu_b=True)
+        G, na, nb = ops.xty(pre0, pre1, relu_a=True, relu_b=True, rows_sharded=True)
         cost = ops.cost_dist(G, na, nb, s0, s1)
         if self.cost_matrices is not None:
             self.cost_matrices.append(cost)

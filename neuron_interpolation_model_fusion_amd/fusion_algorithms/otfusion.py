@@ -93,7 +93,7 @@ class OTFusion:
     def _get_preactivation_cost(act1, act2, normalize=False):
         """Euclidean distance between neuron activation columns, act: (rows, width) on the device
         (otfusion.py:135-150; the reference moves both to the CPU first)."""
-        G, na, nb = ops.xty(act1, act2)
+        G, na, nb = ops.xty(act1, act2, rows_sharded=True)
         if normalize:  # columns scaled to unit norm (fusion_utils.py:38-40) == cosine form of the Gram
             G = G / (na.sqrt()[:, None] * nb.sqrt()[None, :])
             na, nb = torch.ones_like(na), torch.ones_like(nb)

@@ -41,8 +41,12 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
-def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, trans_b=False, norms=True):
+def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, trans_b=False, norms=True,
+        rows_sharded=False):
     """G = A^T B over the rows (f64, n0 x n1) and the squared column norms (f64).
+
+    rows_sharded=True marks a contraction over the fusion samples: inside a
+    parallel.SampleSharding context the outputs are summed over the ranks (one all-reduce).
 
     A: m x n0, B: m x n1 (or n x m when trans_*).  B=None means B is A (symmetric mode).
     acc: 'f32' (exact-f32 MFMA per row block, f64 across blocks) or 'f64' (f64 MFMA).
@@ -74,6 +78,9 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=A.device)
         check(lib.nif_xty(_ptr(A), _ld(A), _ptr(B), _ld(B), m, n0, n1, _DT[A.dtype], accv, flags,
                           _ptr(G), n1, _ptr(na), _ptr(nb), _ptr(ws), nbytes, _stream()), 'nif_xty')
+    if rows_sharded:
+        from .parallel import SampleSharding
+        G, na, nb = SampleSharding.reduce(G, na, nb)
     return G, na, nb
 
 
@@ -199,14 +206,21 @@ def ls_solve(X, A, normalize=False):
     """
     _need_gpu(X, A)
     m, d = X.shape
-    R, _, na = xty(X, A, acc='f64')
+    from .parallel import SampleSharding
+    sharded = SampleSharding._active is not None
+    if sharded:  # m is the GLOBAL row count for pinv's cutoff; the dual form needs every row locally
+        import torch.distributed as dist
+        mt = torch.tensor([m], device=X.device, dtype=torch.int64)
+        dist.all_reduce(mt, group=SampleSharding._active.group)
+        m = int(mt.item())
+    R, _, na = xty(X, A, acc='f64', rows_sharded=True)
     if normalize:
         inv = 1.0 / na.sqrt()
         R = R * inv[None, :]
         na = torch.ones_like(na)
     rtol = max(m, d) * _EPS32
-    if m >= d:
-        G, _, _ = xty(X, None, acc='f64', norms=False)
+    if m >= d or sharded:
+        G, _, _ = xty(X, None, acc='f64', norms=False, rows_sharded=True)
         lam, V = torch.linalg.eigh(G)
         keep = lam > (rtol * rtol) * lam[-1]
         inv_lam = torch.where(keep, 1.0 / lam, torch.zeros_like(lam))

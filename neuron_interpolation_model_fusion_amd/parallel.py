@@ -1,0 +1,85 @@
+"""Sample-sharded fusion over one 8 x MI355X node (no counterpart in the reference, which is
+single-process: SURVEY section 5 / 8e).
+
+The fusion samples (rows of every activation matrix) are split over the ranks, one process per
+GPU.  Every quantity of the path that depends on the samples is a sum over rows -- A^T B, X^T X,
+X^T A, squared column norms -- so each rank builds its partial with the local kernels and ONE
+all-reduce (sum, f64) per level combines the packed [G | na | nb] buffer.  f64 keeps the
+rank-order of the sum from touching the 1e-6 tie margin of the assignments.  What follows the
+reduction (cost epilogue, assignment, k-means on the N x N Gram, refit) is small and replicated:
+every rank computes the identical result from the identical reduced buffer, so no broadcast is
+needed.  torch.distributed's "nccl" backend is RCCL on ROCm; "gloo" runs the same code on CPU
+tensors (tests/test_parallel_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_rows, rank=None, world=None):
+    """Half-open row range [lo, hi) of this rank: contiguous, balanced to within one row."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    return n_rows * rank // world, n_rows * (rank + 1) // world
+
+
+def pack_gram(G, na=None, nb=None):
+    """One contiguous f64 buffer [G.ravel() | na | nb] (a single collective per level)."""
+    parts = [G.reshape(-1).double()]
+    if na is not None:
+        parts.append(na.double())
+    if nb is not None:
+        parts.append(nb.double())
+    return torch.cat(parts)
+
+
+def unpack_gram(buf, n0, n1, has_na=True, has_nb=True):
+    G = buf[:n0 * n1].view(n0, n1)
+    off = n0 * n1
+    na = nb = None
+    if has_na:
+        na = buf[off:off + n0]
+        off += n0
+    if has_nb:
+        nb = buf[off:off + n1]
+    return G, na, nb
+
+
+def allreduce_gram(G, na=None, nb=None, group=None):
+    """Sum the per-rank partial Gram quantities over the group; returns (G, na, nb) views of the
+    reduced buffer.  A no-op when torch.distributed is not initialised or the group has one rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return G, na, nb
+    n0, n1 = G.shape
+    buf = pack_gram(G, na, nb)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return unpack_gram(buf, n0, n1, na is not None, nb is not None)
+
+
+class SampleSharding:
+    """Context: inside it, ops.xty calls whose contraction axis is the sample axis reduce their
+    outputs over `group` (the host classes mark those calls with rows_sharded=True).
+
+        with SampleSharding(group):          # every rank holds its shard of X
+            fused = GitRebasin(m0, m1).fuse(X_local, None, 'uniform')
+    """
+    _active = None
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __enter__(self):
+        self._prev = SampleSharding._active
+        SampleSharding._active = self
+        return self
+
+    def __exit__(self, *exc):
+        SampleSharding._active = self._prev
+        return False
+
+    @classmethod
+    def reduce(cls, G, na=None, nb=None):
+        if cls._active is None:
+            return G, na, nb
+        return allreduce_gram(G, na, nb, cls._active.group)

@@ -1,0 +1,65 @@
+"""not-gpu: the N > 1 host logic on two gloo ranks (CPU tensors): row sharding, the packed
+[G | na | nb] all-reduce, and that the reduced Gram equals the single-process one."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, m, n0, n1, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from neuron_interpolation_model_fusion_amd import parallel
+        g = torch.Generator().manual_seed(0)
+        A = torch.randn(m, n0, generator=g, dtype=torch.float64)
+        B = torch.randn(m, n1, generator=g, dtype=torch.float64)
+        lo, hi = parallel.shard_rows(m)
+        Al, Bl = A[lo:hi], B[lo:hi]
+        G, na, nb = parallel.allreduce_gram(Al.T @ Bl, (Al * Al).sum(0), (Bl * Bl).sum(0))
+        ok = torch.allclose(G, A.T @ B, rtol=1e-12) and torch.allclose(na, (A * A).sum(0), rtol=1e-12) \
+            and torch.allclose(nb, (B * B).sum(0), rtol=1e-12)
+        # the context manager routes the same reduction, and is a no-op outside
+        with parallel.SampleSharding():
+            G2, _, _ = parallel.SampleSharding.reduce(Al.T @ Bl)
+        ok = ok and torch.allclose(G2, A.T @ B, rtol=1e-12)
+        G3, _, _ = parallel.SampleSharding.reduce(Al.T @ Bl)
+        ok = ok and torch.equal(G3, Al.T @ Bl)
+        # every rank ends with bit-identical buffers (replicated assignment needs no broadcast)
+        gathered = [torch.empty_like(G) for _ in range(world)]
+        dist.all_gather(gathered, G.contiguous())
+        ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+        out[rank] = bool(ok) and (lo, hi) == (m * rank // world, m * (rank + 1) // world)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('m,n0,n1', [(101, 7, 5), (64, 16, 16)])
+def test_sharded_gram_allreduce_two_ranks(m, n0, n1):
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), m, n0, n1, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_shard_rows_cover_everything():
+    from neuron_interpolation_model_fusion_amd.parallel import shard_rows, pack_gram, unpack_gram
+    for m in (1, 7, 325000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_rows(m, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == m
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    G, na, nb = torch.arange(6.).view(2, 3), torch.tensor([1., 2.]), torch.tensor([3., 4., 5.])
+    g2, a2, b2 = unpack_gram(pack_gram(G, na, nb), 2, 3)
+    assert torch.equal(g2, G.double()) and torch.equal(a2, na.double()) and torch.equal(b2, nb.double())
