@@ -1,34 +1,36 @@
 // nif_xty.hip -- column cross-Gram G = A^T B over the sample rows, for gfx950.
 //
-// The contraction axis is the ROW axis of the row-major activation matrices, so
-// one output tile is a sum over m rows: the row range is split over workgroups
-// (split-K), each workgroup owns one 128x128 output tile x one row block and
-// writes its partial tile to a slab; a second kernel sums the slabs in a fixed
-// order in f64 (bitwise reproducible, no atomics) and mirrors the lower
-// triangle in symmetric mode.
+// The contraction axis is the ROW axis of the row-major activation matrices, so one output
+// tile is a sum over m rows: the row range is split over workgroups (split-K), each workgroup
+// owns one output tile x one row block and writes its partial tile to a slab; a second kernel
+// sums the slabs in a fixed order in f64 (bitwise reproducible, no atomics), mirrors the lower
+// triangle in symmetric mode and reduces the column-norm partials in the same launch.
 //
 // MFMA mapping (wave64):
-//   f32 accumulate: v_mfma_f32_32x32x2_f32. Lane l feeds A[i = l&31][k = l>>5]:
-//     with row-major activations, lanes 0..31 read 32 consecutive columns of
-//     sample row k and lanes 32..63 the same columns of row k+1 -- the layout
-//     the tiles already have in HBM and LDS, so no transpose anywhere.
+//   f32 accumulate: v_mfma_f32_32x32x2_f32.  Lane l feeds A[i = l&31][k = l>>5]: with row-major
+//     activations, lanes 0..31 read 32 consecutive columns of sample row k and lanes 32..63 the
+//     same columns of row k+1 -- the layout the tiles already have in HBM and in LDS, so there
+//     is no transpose anywhere.
 //   f64 accumulate: v_mfma_f64_16x16x4_f64, lane l feeds A[i = l&15][k = l>>4].
-// A workgroup is 4 waves (2x2), each wave a 64x64 sub-tile; tiles are staged
-// through LDS in [BK=16][144]-element images (row stride 144 keeps the 16-lane
-// groups of the f64 path on distinct banks), double-buffered, global loads for
-// tile t+1 issued before the MFMAs of tile t and written to LDS after them.
+// A workgroup is 4 waves (2 x 2); a wave owns (32 FI) x (32 FJ) outputs, the workgroup tile is
+// (64 FI) x (64 FJ): FI = FJ = 2 (128 x 128, 64 accumulator registers, 4 waves/SIMD) or, f32
+// only, FI = FJ = 3 (192 x 192, 144 accumulator registers, 2 waves/SIMD: 9 MFMAs per 6 operand
+// reads and per barrier instead of 4 per 4).  Tiles are staged through LDS as [BK = 16][TM + 16]
+// images (the +16 keeps the 16-lane groups of the f64 form on distinct banks), double-buffered;
+// the global loads of tile t+1 are issued before the MFMAs of tile t and its LDS writes and
+// norm updates are spread between the MFMA groups of tile t (one barrier per tile).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "../../include/nif.h"
 #include "nif_common.h"
 
 namespace nif {
 
-constexpr int TM = 128;
-constexpr int TN = 128;
 constexpr int BK = 16;
-constexpr int LDS_LD = 144;
 constexpr int NT = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,10 +45,8 @@ struct XtyArgs {
   int flags;
   int vec_a, vec_b;  // 16-byte vector loads are legal for this operand
   void* slab;        // [splits][n0p][n1p] accumulator type
-  float* nslab_a;    // [splits][n0p] partial squared column norms (f32 in / f32 acc) ...
-  float* nslab_b;    // [splits][n1p]
-  double* dslab_a;   // ... or f64 when accumulating in f64
-  double* dslab_b;
+  void* nslab_a;     // [splits][n0p] partial squared column norms, accumulator type
+  void* nslab_b;     // [splits][n1p]
 };
 
 template <typename T>
@@ -54,142 +54,201 @@ struct V4 {
   T v[4];
 };
 
-// ---- global -> register staging ------------------------------------------------
-
-// Non-transposed operand: tile element (k, c) = P[(k0 + k) * ld + c0 + c].
-// Thread t stages columns 4*(t%32)..+3 of rows t/32 and t/32 + 8.
-template <typename T, bool RELU>
-__device__ __forceinline__ void stage_rows(V4<T> (&r)[2], const T* __restrict__ P, int64_t ld, int64_t k0,
-                                           int64_t kend, int c0, int n, int vec_ok, int tid) {
-  const int col = c0 + 4 * (tid & 31);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int64_t row = k0 + (tid >> 5) + 8 * h;
-    V4<T> x;
-    x.v[0] = x.v[1] = x.v[2] = x.v[3] = T(0);
-    if (row < kend && col < n) {
-      const T* p = P + row * ld + col;
-      if (vec_ok && col + 3 < n) {
-        if constexpr (sizeof(T) == 4) {
-          const float4 q = *reinterpret_cast<const float4*>(p);
-          x.v[0] = q.x; x.v[1] = q.y; x.v[2] = q.z; x.v[3] = q.w;
-        } else {
-          const double2 q0 = *reinterpret_cast<const double2*>(p);
-          const double2 q1 = *reinterpret_cast<const double2*>(p + 2);
-          x.v[0] = q0.x; x.v[1] = q0.y; x.v[2] = q1.x; x.v[3] = q1.y;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (col + e < n) x.v[e] = p[e];
-      }
-      if (RELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x.v[e] = x.v[e] > T(0) ? x.v[e] : T(0);
-      }
-    }
-    r[h] = x;
-  }
-}
-
-// Transposed operand (stored n x m): tile element (k, c) = P[(c0 + c) * ld + k0 + k].
-// Thread t stages k = 4*(t%4)..+3 of columns t/4 and t/4 + 64.
-template <typename T, bool RELU>
-__device__ __forceinline__ void stage_cols(V4<T> (&r)[2], const T* __restrict__ P, int64_t ld, int64_t k0,
-                                           int64_t kend, int c0, int n, int vec_ok, int tid) {
-  const int64_t k = k0 + 4 * (tid & 3);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = c0 + (tid >> 2) + 64 * h;
-    V4<T> x;
-    x.v[0] = x.v[1] = x.v[2] = x.v[3] = T(0);
-    if (c < n && k < kend) {
-      const T* p = P + (int64_t)c * ld + k;
-      if (vec_ok && k + 3 < kend) {
-        if constexpr (sizeof(T) == 4) {
-          const float4 q = *reinterpret_cast<const float4*>(p);
-          x.v[0] = q.x; x.v[1] = q.y; x.v[2] = q.z; x.v[3] = q.w;
-        } else {
-          const double2 q0 = *reinterpret_cast<const double2*>(p);
-          const double2 q1 = *reinterpret_cast<const double2*>(p + 2);
-          x.v[0] = q0.x; x.v[1] = q0.y; x.v[2] = q1.x; x.v[3] = q1.y;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < kend) x.v[e] = p[e];
-      }
-      if (RELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x.v[e] = x.v[e] > T(0) ? x.v[e] : T(0);
-      }
-    }
-    r[h] = x;
-  }
-}
-
 template <typename T>
-__device__ __forceinline__ void lds_put_rows(T* __restrict__ L, const V4<T> (&r)[2], int tid) {
-  // 16-byte aligned: LDS_LD * sizeof(T) and 4 * sizeof(T) are multiples of 16
+__device__ __forceinline__ void load4(V4<T>& x, const T* __restrict__ p) {
+  if constexpr (sizeof(T) == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    x.v[0] = q.x; x.v[1] = q.y; x.v[2] = q.z; x.v[3] = q.w;
+  } else {
+    const double2 q0 = *reinterpret_cast<const double2*>(p);
+    const double2 q1 = *reinterpret_cast<const double2*>(p + 2);
+    x.v[0] = q0.x; x.v[1] = q0.y; x.v[2] = q1.x; x.v[3] = q1.y;
+  }
+}
+
+// ---- global -> register staging of one [BK][W] operand tile ------------------------------------
+// W = tile width in columns.  Row-major operand: element (k, c) = P[(k0 + k) * ld + c0 + c]; the
+// tile is BK * W / 4 four-element pieces, piece idx = tid + 256 h -> row idx / (W/4), columns
+// 4 (idx % (W/4)) .. +3.  Interior tiles (all rows and columns in range, 16-byte loads legal)
+// take a branch-free path; that test is block-uniform (a scalar branch).
+template <typename T, int W, bool RELU>
+struct StageRows {
+  static constexpr int C4 = W / 4;
+  static constexpr int PASSES = BK * C4 / NT;
+  static_assert(BK * C4 % NT == 0, "tile must split evenly over the workgroup");
+  static constexpr int PARTS = BK;  // norm partials per column: one per tile row
+
+  static __device__ __forceinline__ void load(V4<T> (&r)[PASSES], const T* __restrict__ P, int64_t ld, int64_t k0,
+                                              int64_t kend, int c0, int n, int vec_ok, int tid) {
+    const bool interior = vec_ok && (c0 + W <= n) && (k0 + BK <= kend);
+    if (interior) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    T* d = L + ((tid >> 5) + 8 * h) * LDS_LD + 4 * (tid & 31);
-    if constexpr (sizeof(T) == 4) {
-      *reinterpret_cast<float4*>(d) = make_float4(r[h].v[0], r[h].v[1], r[h].v[2], r[h].v[3]);
+      for (int h = 0; h < PASSES; ++h) {
+        const int idx = tid + NT * h;
+        load4(r[h], P + (k0 + idx / C4) * ld + c0 + 4 * (idx % C4));
+      }
     } else {
-      *reinterpret_cast<double2*>(d) = make_double2(r[h].v[0], r[h].v[1]);
-      *reinterpret_cast<double2*>(d + 2) = make_double2(r[h].v[2], r[h].v[3]);
+#pragma unroll
+      for (int h = 0; h < PASSES; ++h) {
+        const int idx = tid + NT * h;
+        const int64_t row = k0 + idx / C4;
+        const int col = c0 + 4 * (idx % C4);
+        V4<T> x;
+        x.v[0] = x.v[1] = x.v[2] = x.v[3] = T(0);
+        if (row < kend && col < n) {
+          const T* p = P + row * ld + col;
+          if (vec_ok && col + 3 < n) {
+            load4(x, p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < n) x.v[e] = p[e];
+          }
+        }
+        r[h] = x;
+      }
+    }
+    if (RELU) {
+#pragma unroll
+      for (int h = 0; h < PASSES; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[h].v[e] = r[h].v[e] > T(0) ? r[h].v[e] : T(0);
     }
   }
-}
 
-template <typename T>
-__device__ __forceinline__ void lds_put_cols(T* __restrict__ L, const V4<T> (&r)[2], int tid) {
+  template <int LD>
+  static __device__ __forceinline__ void put(T* __restrict__ L, const V4<T> (&r)[PASSES], int tid) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = (tid >> 2) + 64 * h;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) L[(4 * (tid & 3) + e) * LDS_LD + c] = r[h].v[e];
+    for (int h = 0; h < PASSES; ++h) {
+      const int idx = tid + NT * h;
+      T* d = L + (idx / C4) * LD + 4 * (idx % C4);  // 16-byte aligned: LD and 4 are multiples of 4 elements
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(d) = make_float4(r[h].v[0], r[h].v[1], r[h].v[2], r[h].v[3]);
+      } else {
+        *reinterpret_cast<double2*>(d) = make_double2(r[h].v[0], r[h].v[1]);
+        *reinterpret_cast<double2*>(d + 2) = make_double2(r[h].v[2], r[h].v[3]);
+      }
+    }
   }
-}
 
-// ---- matrix-core micro kernels ---------------------------------------------------
+  // squared-norm partials: sq[h][e] belongs to column 4 (idx % C4) + e, part idx / C4
+  template <typename acc_t>
+  static __device__ __forceinline__ void norms(acc_t (&sq)[PASSES][4], const V4<T> (&r)[PASSES]) {
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sq[h][e] += (acc_t)r[h].v[e] * (acc_t)r[h].v[e];
+  }
+  template <typename acc_t>
+  static __device__ __forceinline__ void norms_to_lds(acc_t* __restrict__ red, const acc_t (&sq)[PASSES][4], int tid) {
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) {
+      const int idx = tid + NT * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[(idx / C4) * W + 4 * (idx % C4) + e] = sq[h][e];
+    }
+  }
+};
 
+// Transposed operand (stored n x m): element (k, c) = P[(c0 + c) * ld + k0 + k]; pieces run along
+// k: piece idx -> column idx / (BK/4), k = 4 (idx % (BK/4)) .. +3.
+template <typename T, int W, bool RELU>
+struct StageCols {
+  static constexpr int K4 = BK / 4;
+  static constexpr int PASSES = W * K4 / NT;
+  static_assert(W * K4 % NT == 0, "tile must split evenly over the workgroup");
+  static constexpr int PARTS = K4;
+
+  static __device__ __forceinline__ void load(V4<T> (&r)[PASSES], const T* __restrict__ P, int64_t ld, int64_t k0,
+                                              int64_t kend, int c0, int n, int vec_ok, int tid) {
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) {
+      const int idx = tid + NT * h;
+      const int c = c0 + idx / K4;
+      const int64_t k = k0 + 4 * (idx % K4);
+      V4<T> x;
+      x.v[0] = x.v[1] = x.v[2] = x.v[3] = T(0);
+      if (c < n && k < kend) {
+        const T* p = P + (int64_t)c * ld + k;
+        if (vec_ok && k + 3 < kend) {
+          load4(x, p);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kend) x.v[e] = p[e];
+        }
+      }
+      r[h] = x;
+    }
+  }
+
+  template <int LD>
+  static __device__ __forceinline__ void put(T* __restrict__ L, const V4<T> (&r)[PASSES], int tid) {
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) {
+      const int idx = tid + NT * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) L[(4 * (idx % K4) + e) * LD + idx / K4] = r[h].v[e];
+    }
+  }
+
+  // sq[h][0] sums the piece's four k; column idx / K4, part idx % K4
+  template <typename acc_t>
+  static __device__ __forceinline__ void norms(acc_t (&sq)[PASSES][4], const V4<T> (&r)[PASSES]) {
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sq[h][0] += (acc_t)r[h].v[e] * (acc_t)r[h].v[e];
+  }
+  template <typename acc_t>
+  static __device__ __forceinline__ void norms_to_lds(acc_t* __restrict__ red, const acc_t (&sq)[PASSES][4], int tid) {
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) {
+      const int idx = tid + NT * h;
+      red[(idx % K4) * W + idx / K4] = sq[h][0];
+    }
+  }
+};
+
+// ---- matrix-core micro kernels: a wave's (32 FI) x (32 FJ) tile ----------------------------------
+
+template <int FI, int FJ>
 struct MmaF32 {
   typedef float acc_t;
   typedef f32x16 frag_t;
-  static constexpr int R = 2;  // 32-wide fragments per 64-wide wave tile
-  template <typename T>
-  static __device__ __forceinline__ void tile(const T* __restrict__ la, const T* __restrict__ lb, frag_t (&acc)[R][R],
-                                              int lane) {
+  static constexpr int RI = FI, RJ = FJ;  // 32-wide fragments
+  static constexpr int KSTEPS = BK / 2;
+  typedef float op_t;
+  // operand fragments of k-step kk: lane l reads column (l & 31) + 32 i of tile row 2 kk + (l >> 5)
+  template <typename T, int LDA, int LDB>
+  static __device__ __forceinline__ void load(const T* __restrict__ la, const T* __restrict__ lb, int kk,
+                                              op_t (&a)[RI], op_t (&b)[RJ], int lane) {
+    const int krow = 2 * kk + (lane >> 5);
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const int off = (2 * kk + (lane >> 5)) * LDS_LD + (lane & 31);
-      float a[R], b[R];
+    for (int i = 0; i < RI; ++i) a[i] = (float)la[krow * LDA + (lane & 31) + 32 * i];
 #pragma unroll
-      for (int i = 0; i < R; ++i) a[i] = (float)la[off + 32 * i];
-#pragma unroll
-      for (int j = 0; j < R; ++j) b[j] = (float)lb[off + 32 * j];
-#pragma unroll
-      for (int i = 0; i < R; ++i)
-#pragma unroll
-        for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    for (int j = 0; j < RJ; ++j) b[j] = (float)lb[krow * LDB + (lane & 31) + 32 * j];
   }
-  static __device__ __forceinline__ void zero(frag_t (&acc)[R][R]) {
+  static __device__ __forceinline__ void mma(const op_t (&a)[RI], const op_t (&b)[RJ], frag_t (&acc)[RI][RJ]) {
 #pragma unroll
-    for (int i = 0; i < R; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
-      for (int j = 0; j < R; ++j)
+      for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  static __device__ __forceinline__ void zero(frag_t (&acc)[RI][RJ]) {
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < RJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   }
   // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  static __device__ __forceinline__ void store(acc_t* __restrict__ S, int ld, const frag_t (&acc)[R][R], int lane) {
+  static __device__ __forceinline__ void store(acc_t* __restrict__ S, int ld, const frag_t (&acc)[RI][RJ], int lane) {
 #pragma unroll
-    for (int i = 0; i < R; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
-      for (int j = 0; j < R; ++j)
+      for (int j = 0; j < RJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -198,41 +257,42 @@ struct MmaF32 {
   }
 };
 
+template <int FI, int FJ>
 struct MmaF64 {
   typedef double acc_t;
   typedef f64x4 frag_t;
-  static constexpr int R = 4;  // 16-wide fragments per 64-wide wave tile
-  template <typename T>
-  static __device__ __forceinline__ void tile(const T* __restrict__ la, const T* __restrict__ lb, frag_t (&acc)[R][R],
-                                              int lane) {
+  static constexpr int RI = 2 * FI, RJ = 2 * FJ;  // 16-wide fragments
+  static constexpr int KSTEPS = BK / 4;
+  typedef double op_t;
+  template <typename T, int LDA, int LDB>
+  static __device__ __forceinline__ void load(const T* __restrict__ la, const T* __restrict__ lb, int kk,
+                                              op_t (&a)[RI], op_t (&b)[RJ], int lane) {
+    const int krow = 4 * kk + (lane >> 4);
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const int off = (4 * kk + (lane >> 4)) * LDS_LD + (lane & 15);
-      double a[R], b[R];
+    for (int i = 0; i < RI; ++i) a[i] = (double)la[krow * LDA + (lane & 15) + 16 * i];
 #pragma unroll
-      for (int i = 0; i < R; ++i) a[i] = (double)la[off + 16 * i];
-#pragma unroll
-      for (int j = 0; j < R; ++j) b[j] = (double)lb[off + 16 * j];
-#pragma unroll
-      for (int i = 0; i < R; ++i)
-#pragma unroll
-        for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    for (int j = 0; j < RJ; ++j) b[j] = (double)lb[krow * LDB + (lane & 15) + 16 * j];
   }
-  static __device__ __forceinline__ void zero(frag_t (&acc)[R][R]) {
+  static __device__ __forceinline__ void mma(const op_t (&a)[RI], const op_t (&b)[RJ], frag_t (&acc)[RI][RJ]) {
 #pragma unroll
-    for (int i = 0; i < R; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
-      for (int j = 0; j < R; ++j)
+      for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  static __device__ __forceinline__ void zero(frag_t (&acc)[RI][RJ]) {
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < RJ; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
   }
   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
-  static __device__ __forceinline__ void store(acc_t* __restrict__ S, int ld, const frag_t (&acc)[R][R], int lane) {
+  static __device__ __forceinline__ void store(acc_t* __restrict__ S, int ld, const frag_t (&acc)[RI][RJ], int lane) {
 #pragma unroll
-    for (int i = 0; i < R; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
-      for (int j = 0; j < R; ++j)
+      for (int j = 0; j < RJ; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * i + (lane >> 4) + 4 * e;
@@ -241,24 +301,36 @@ struct MmaF64 {
   }
 };
 
-// ---- main kernel -----------------------------------------------------------------
+// ---- main kernel -----------------------------------------------------------------------------------
 
-template <typename Tin, typename Mma, bool RELU_A, bool RELU_B, bool TA, bool TB>
-__global__ __launch_bounds__(NT) void xty_kernel(const XtyArgs p) {
+// waves per SIMD the register budget is sized for: 4 for the 128-wide f32 tile (64 accumulator
+// registers), 2 for the 192-wide f32 tile and for the f64 forms
+template <template <int, int> class MmaT, int FI>
+constexpr int xty_waves_per_simd() {
+  return (sizeof(typename MmaT<FI, FI>::acc_t) == 4 && FI == 2) ? 4 : 2;
+}
+
+template <typename Tin, template <int, int> class MmaT, int FI, int FJ, bool RELU_A, bool RELU_B, bool TA, bool TB>
+__global__ __launch_bounds__(NT, (xty_waves_per_simd<MmaT, FI>())) void xty_kernel(const XtyArgs p) {
+  typedef MmaT<FI, FJ> Mma;
   typedef typename Mma::acc_t acc_t;
+  constexpr int TM = 64 * FI, TN = 64 * FJ;
+  constexpr int LDA = TM + 16, LDB = TN + 16;
+  constexpr int TILE_A = BK * LDA, TILE_B = BK * LDB;
+  typedef typename std::conditional<TA, StageCols<Tin, TM, RELU_A>, StageRows<Tin, TM, RELU_A>>::type SA;
+  typedef typename std::conditional<TB, StageCols<Tin, TN, RELU_B>, StageRows<Tin, TN, RELU_B>>::type SB;
+
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Tin* smem = reinterpret_cast<Tin*>(smem_raw);
-  // [buf][operand][BK][LDS_LD]
-  constexpr int TILE = BK * LDS_LD;
+  Tin* smem = reinterpret_cast<Tin*>(smem_raw);  // [buf]{A[BK][LDA], B[BK][LDB]}
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
 
-  // XCD-aware id remap (bijective for any grid size): blocks b and b + 8 share an
-  // XCD, so give each XCD a contiguous range of ids; consecutive ids are the tiles
-  // of one row block and reuse its A / B panels out of that XCD's L2.
+  // XCD-aware id remap (bijective for any grid size): blocks b and b + 8 share an XCD, so give
+  // each XCD a contiguous range of ids; consecutive ids are the tiles of one row block and reuse
+  // its A / B panels out of that XCD's L2.
   const int nwg = gridDim.x;
   const int orig = blockIdx.x;
   const int xcd = orig & 7;
@@ -291,145 +363,166 @@ __global__ __launch_bounds__(NT) void xty_kernel(const XtyArgs p) {
   const Tin* A = reinterpret_cast<const Tin*>(p.A);
   const Tin* B = reinterpret_cast<const Tin*>(p.B);
 
-  typename Mma::frag_t acc[Mma::R][Mma::R];
+  typename Mma::frag_t acc[Mma::RI][Mma::RJ];
   Mma::zero(acc);
 
-  // squared-norm partials of the staged elements
-  acc_t sqa[4] = {0, 0, 0, 0}, sqb[4] = {0, 0, 0, 0};
+  // column-norm partials are only kept by the blocks that publish them: A's from tile column 0
+  // (the diagonal in symmetric mode), B's from tile row 0
+  const bool want_a = (p.flags & NIF_SYMMETRIC) ? (ti == tj) : (tj == 0);
+  const bool want_b = !(p.flags & NIF_SYMMETRIC) && (ti == 0);
+  acc_t sqa[SA::PASSES][4], sqb[SB::PASSES][4];
+#pragma unroll
+  for (int h = 0; h < SA::PASSES; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sqa[h][e] = 0;
+#pragma unroll
+  for (int h = 0; h < SB::PASSES; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sqb[h][e] = 0;
 
-  V4<Tin> ra[2], rb[2];
-  auto stage = [&](int64_t k0) {
-    if (TA) stage_cols<Tin, RELU_A>(ra, A, p.lda, k0, k_end, ci, p.n0, p.vec_a, tid);
-    else stage_rows<Tin, RELU_A>(ra, A, p.lda, k0, k_end, ci, p.n0, p.vec_a, tid);
-    if (TB) stage_cols<Tin, RELU_B>(rb, B, p.ldb, k0, k_end, cj, p.n1, p.vec_b, tid);
-    else stage_rows<Tin, RELU_B>(rb, B, p.ldb, k0, k_end, cj, p.n1, p.vec_b, tid);
+  // A's and B's staging registers have disjoint lifetimes in the main loop (A: loaded at the top of
+  // an iteration, written to LDS at k-step KA; B: loaded right after that, written at KB2), so they
+  // share physical registers.
+  V4<Tin> ra[SA::PASSES], rb[SB::PASSES];
+  auto stage_a = [&](int64_t k0) { SA::load(ra, A, p.lda, k0, k_end, ci, p.n0, p.vec_a, tid); };
+  auto stage_b = [&](int64_t k0) { SB::load(rb, B, p.ldb, k0, k_end, cj, p.n1, p.vec_b, tid); };
+  auto commit_a = [&](int buf) {
+    SA::template put<LDA>(smem + buf * (TILE_A + TILE_B), ra, tid);
+    if (want_a) SA::norms(sqa, ra);
   };
-  auto commit = [&](int buf) {
-    Tin* la = smem + (buf * 2 + 0) * TILE;
-    Tin* lb = smem + (buf * 2 + 1) * TILE;
-    if (TA) lds_put_cols<Tin>(la, ra, tid); else lds_put_rows<Tin>(la, ra, tid);
-    if (TB) lds_put_cols<Tin>(lb, rb, tid); else lds_put_rows<Tin>(lb, rb, tid);
-    if (TA) {
-      // two columns per thread: sq[h] sums that column's 4 staged k
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sqa[h] += (acc_t)ra[h].v[e] * (acc_t)ra[h].v[e];
-    } else {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sqa[e] += (acc_t)ra[h].v[e] * (acc_t)ra[h].v[e];
-    }
-    if (TB) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sqb[h] += (acc_t)rb[h].v[e] * (acc_t)rb[h].v[e];
-    } else {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sqb[e] += (acc_t)rb[h].v[e] * (acc_t)rb[h].v[e];
-    }
+  auto commit_b = [&](int buf) {
+    SB::template put<LDB>(smem + buf * (TILE_A + TILE_B) + TILE_A, rb, tid);
+    if (want_b) SB::norms(sqb, rb);
   };
 
   if (nt > 0) {
-    stage(k_begin);
-    commit(0);
+    stage_a(k_begin);
+    commit_a(0);
+    stage_b(k_begin);
+    commit_b(0);
   }
   __syncthreads();
+  // Software pipeline inside every wave.  (1) All waves of a CU run this program in near lock-step,
+  // so a separate staging phase would idle the matrix pipe in every wave at once: the LDS writes and
+  // norm updates of tile t+1 sit between the MFMA groups of tile t.  (2) A wave issues in order, so
+  // operand reads placed after an MFMA group only start once its last MFMA has ISSUED and their
+  // latency is exposed: the fragments of k-step kk+1 are requested before the MFMAs of step kk.
+  constexpr int KS = Mma::KSTEPS;
+  constexpr int KA = KS / 4, KB2 = KS - 1;
+  typename Mma::op_t fa[2][Mma::RI], fb[2][Mma::RJ];
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nt) stage(k_begin + (int64_t)(t + 1) * BK);
-    const Tin* la = smem + (buf * 2 + 0) * TILE + wi * 64;
-    const Tin* lb = smem + (buf * 2 + 1) * TILE + wj * 64;
-    Mma::template tile<Tin>(la, lb, acc, lane);
-    if (t + 1 < nt) commit(buf ^ 1);
+    const bool more = t + 1 < nt;
+    const int64_t knext = k_begin + (int64_t)(t + 1) * BK;
+    if (more) stage_a(knext);
+    const Tin* la = smem + buf * (TILE_A + TILE_B) + wi * (TM / 2);
+    const Tin* lb = smem + buf * (TILE_A + TILE_B) + TILE_A + wj * (TN / 2);
+    Mma::template load<Tin, LDA, LDB>(la, lb, 0, fa[0], fb[0], lane);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      if (kk + 1 < KS) Mma::template load<Tin, LDA, LDB>(la, lb, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1], lane);
+      if (kk == KA && more) {
+        commit_a(buf ^ 1);
+        stage_b(knext);
+      }
+      if (kk == KB2 && more) commit_b(buf ^ 1);
+      Mma::mma(fa[kk & 1], fb[kk & 1], acc);
+      __builtin_amdgcn_sched_barrier(0);  // keep the one-step prefetch distance: no hoisting of later reads
+    }
     __syncthreads();
   }
 
   // partial tile -> slab (padded to whole tiles, so no guards)
-  acc_t* S = reinterpret_cast<acc_t*>(p.slab) + ((int64_t)split * p.n0p + ci + wi * 64) * p.n1p + cj + wj * 64;
+  acc_t* S = reinterpret_cast<acc_t*>(p.slab) + ((int64_t)split * p.n0p + ci + wi * (TM / 2)) * p.n1p + cj + wj * (TN / 2);
   Mma::store(S, p.n1p, acc, lane);
 
-  // column-norm partials: A's from the blocks of tile column 0 (or the diagonal
-  // in symmetric mode), B's from tile row 0.  Fixed summation order.
-  const bool want_a = (p.flags & NIF_SYMMETRIC) ? (ti == tj) : (tj == 0);
-  const bool want_b = !(p.flags & NIF_SYMMETRIC) && (ti == 0);
-  acc_t* red = reinterpret_cast<acc_t*>(smem_raw);  // [8][128], the tile images are dead now
-  auto reduce_norm = [&](const acc_t (&sq)[4], bool trans, int c0, int npad, float* fslab, double* dslab) {
-    int parts;
-    if (trans) {
-      parts = 4;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) red[(tid & 3) * 128 + (tid >> 2) + 64 * h] = sq[h];
-    } else {
-      parts = 8;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) red[(tid >> 5) * 128 + 4 * (tid & 31) + e] = sq[e];
-    }
+  // column-norm partials, fixed summation order; the tile images are dead after the last barrier
+  acc_t* red = reinterpret_cast<acc_t*>(smem_raw);
+  if (want_a) {
+    SA::norms_to_lds(red, sqa, tid);
     __syncthreads();
-    if (tid < 128) {
+    if (tid < TM) {
       acc_t s = 0;
-      for (int r = 0; r < parts; ++r) s += red[r * 128 + tid];
-      if constexpr (sizeof(acc_t) == 4) fslab[(int64_t)split * npad + c0 + tid] = s;
-      else dslab[(int64_t)split * npad + c0 + tid] = s;
+      for (int r = 0; r < SA::PARTS; ++r) s += red[r * TM + tid];
+      reinterpret_cast<acc_t*>(p.nslab_a)[(int64_t)split * p.n0p + ci + tid] = s;
     }
     __syncthreads();
-  };
-  if (want_a) reduce_norm(sqa, TA, ci, p.n0p, p.nslab_a, p.dslab_a);
-  if (want_b) reduce_norm(sqb, TB, cj, p.n1p, p.nslab_b, p.dslab_b);
+  }
+  if (want_b) {
+    SB::norms_to_lds(red, sqb, tid);
+    __syncthreads();
+    if (tid < TN) {
+      acc_t s = 0;
+      for (int r = 0; r < SB::PARTS; ++r) s += red[r * TN + tid];
+      reinterpret_cast<acc_t*>(p.nslab_b)[(int64_t)split * p.n1p + cj + tid] = s;
+    }
+  }
 }
 
-// ---- slab reduction --------------------------------------------------------------
-
+// ---- slab + norm reduction, one launch --------------------------------------------------------------
+// blockIdx.y < n0: row i of G (threads along j); blockIdx.y == n0: na; == n0 + 1: nb.
 template <typename acc_t>
-__global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, int splits, int n0, int n1, int n0p, int n1p,
-                                  int symmetric, double* __restrict__ G, int64_t ldg) {
+__global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* __restrict__ nsa,
+                                  const acc_t* __restrict__ nsb, int splits, int n0, int n1, int n0p, int n1p,
+                                  int tm, int symmetric, double* __restrict__ G, int64_t ldg,
+                                  double* __restrict__ na, double* __restrict__ nb) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y;
-  if (j >= n1 || i >= n0) return;
-  int si = i, sj = j;
-  if (symmetric && (i / TM) > (j / TN)) {
-    si = j;
-    sj = i;
+  if (i < n0) {
+    if (j >= n1) return;
+    int si = i, sj = j;
+    if (symmetric && (i / tm) > (j / tm)) {
+      si = j;
+      sj = i;
+    }
+    const acc_t* s = slab + (int64_t)si * n1p + sj;
+    const int64_t stride = (int64_t)n0p * n1p;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four chains: fixed order, more loads in flight
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      s0 += (double)s[(k + 0) * stride];
+      s1 += (double)s[(k + 1) * stride];
+      s2 += (double)s[(k + 2) * stride];
+      s3 += (double)s[(k + 3) * stride];
+    }
+    for (; k < splits; ++k) s0 += (double)s[k * stride];
+    G[(int64_t)i * ldg + j] = (s0 + s1) + (s2 + s3);
+  } else {
+    const bool is_a = i == n0;
+    double* out = is_a ? na : nb;
+    const int n = is_a ? n0 : n1;
+    if (out == nullptr || j >= n) return;
+    const acc_t* ns = (is_a || symmetric) ? nsa : nsb;
+    const int npad = (is_a || symmetric) ? n0p : n1p;
+    double sum = 0.0;
+    for (int k = 0; k < splits; ++k) sum += (double)ns[(int64_t)k * npad + j];
+    out[j] = sum;
   }
-  const acc_t* s = slab + (int64_t)si * n1p + sj;
-  const int64_t stride = (int64_t)n0p * n1p;
-  double sum = 0.0;
-  for (int k = 0; k < splits; ++k) sum += (double)s[k * stride];
-  G[(int64_t)i * ldg + j] = sum;
 }
 
-template <typename acc_t>
-__global__ void xty_norm_reduce_kernel(const acc_t* __restrict__ ns, int splits, int n, int npad,
-                                       double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double sum = 0.0;
-  for (int k = 0; k < splits; ++k) sum += (double)ns[(int64_t)k * npad + i];
-  out[i] = sum;
-}
-
-// ---- host side -------------------------------------------------------------------
+// ---- host side -------------------------------------------------------------------------------------
 
 struct XtyPlan {
-  int tiles_i, tiles_j, ntiles, splits, n0p, n1p;
+  int f;  // fragments per wave per axis: 2 (128-wide tiles) or 3 (192-wide)
+  int tm, tiles_i, tiles_j, ntiles, splits, n0p, n1p, slots;
   int64_t rows_per_split;
-  size_t slab_bytes, nsa_bytes, nsb_bytes;
+  size_t slab_bytes, nsa_bytes, nsb_bytes, lds_bytes;
 };
 
-static XtyPlan make_plan(int64_t m, int n0, int n1, int acc, int flags) {
+static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, int flags) {
   XtyPlan pl;
-  pl.tiles_i = (n0 + TM - 1) / TM;
-  pl.tiles_j = (n1 + TN - 1) / TN;
-  pl.n0p = pl.tiles_i * TM;
-  pl.n1p = pl.tiles_j * TN;
+  pl.f = f;
+  pl.tm = 64 * f;
+  pl.tiles_i = (n0 + pl.tm - 1) / pl.tm;
+  pl.tiles_j = (n1 + pl.tm - 1) / pl.tm;
+  pl.n0p = pl.tiles_i * pl.tm;
+  pl.n1p = pl.tiles_j * pl.tm;
   pl.ntiles = (flags & NIF_SYMMETRIC) ? pl.tiles_i * (pl.tiles_i + 1) / 2 : pl.tiles_i * pl.tiles_j;
-  // fill the chip (256 CUs, up to 4 resident workgroups each) without leaving a
-  // second, nearly empty round of workgroups; keep >= 4 K-tiles per row block.
-  const int64_t target = 1024;
+  // fill the chip (256 CUs x resident workgroups per CU) without leaving a second, nearly empty
+  // round of workgroups; keep >= 4 K-tiles per row block
+  pl.slots = 256 * (f == 3 ? 2 : (in_f64 || acc == NIF_F64 ? 2 : 4));
+  int64_t target = pl.slots;
+  if (pl.ntiles > target) target = pl.ntiles;
   int64_t splits = target / pl.ntiles;
   const int64_t max_splits = (m + 4 * BK - 1) / (4 * BK);
   if (splits > max_splits) splits = max_splits;
@@ -445,21 +538,47 @@ static XtyPlan make_plan(int64_t m, int n0, int n1, int acc, int flags) {
   pl.slab_bytes = (size_t)pl.splits * pl.n0p * pl.n1p * esz;
   pl.nsa_bytes = (size_t)pl.splits * pl.n0p * esz;
   pl.nsb_bytes = (size_t)pl.splits * pl.n1p * esz;
+  const size_t tiles = (size_t)2 * 2 * BK * (pl.tm + 16) * (in_f64 ? 8 : 4);
+  const size_t red = (size_t)BK * pl.tm * esz;  // norm reduction scratch aliases the tile images
+  pl.lds_bytes = tiles > red ? tiles : red;
   return pl;
+}
+
+// Estimated duration in arbitrary units: rounds of resident workgroups x work per workgroup / the
+// tile shape's measured MFMA efficiency (192-wide tiles run ~1.12x the rate of 128-wide ones).
+static double plan_cost(const XtyPlan& pl) {
+  const int64_t nblocks = (int64_t)pl.ntiles * pl.splits;
+  const int64_t rounds = (nblocks + pl.slots - 1) / pl.slots;
+  const double per_block = (double)pl.rows_per_split * pl.tm * pl.tm;
+  // a round keeps `slots` workgroups resident; fewer resident workgroups per CU each run faster
+  const double speed = (pl.f == 3 ? 1.12 : 1.0) / (pl.slots / 256);
+  return (double)rounds * per_block / speed;
+}
+
+static XtyPlan make_plan(int64_t m, int n0, int n1, int in_f64, int acc, int flags) {
+  XtyPlan p2 = plan_for(2, m, n0, n1, in_f64, acc, flags);
+  if (acc != NIF_F32) return p2;  // the 192-wide tile exists for the f32 matrix path only
+  XtyPlan p3 = plan_for(3, m, n0, n1, in_f64, acc, flags);
+  if (const char* f = getenv("NIF_XTY_FRAGS")) {  // tuning aid
+    const int v = atoi(f);
+    if (v == 2) return p2;
+    if (v == 3) return p3;
+  }
+  return plan_cost(p3) < plan_cost(p2) ? p3 : p2;
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <typename Tin, typename Mma>
+template <typename Tin, template <int, int> class MmaT, int F>
 static void launch_variant(const XtyArgs& a, int nblocks, size_t lds, hipStream_t st) {
   const bool ra = a.flags & NIF_RELU_A, rb = a.flags & NIF_RELU_B;
   const bool ta = a.flags & NIF_TRANS_A, tb = a.flags & NIF_TRANS_B;
-#define NIF_XTY_GO(RA, RB, TA_, TB_)                                                                          \
-  do {                                                                                                        \
-    auto kfn = xty_kernel<Tin, Mma, RA, RB, TA_, TB_>;                                                        \
-    if (lds > 48 * 1024)                                                                                      \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(NT), lds, st, a);                                             \
+#define NIF_XTY_GO(RA, RB, TA_, TB_)                                                                     \
+  do {                                                                                                   \
+    auto kfn = xty_kernel<Tin, MmaT, F, F, RA, RB, TA_, TB_>;                                            \
+    if (lds > 48 * 1024)                                                                                 \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(NT), lds, st, a);                                        \
   } while (0)
   if (!ta && !tb) {
     if (ra && rb) NIF_XTY_GO(true, true, false, false);
@@ -479,8 +598,15 @@ static void launch_variant(const XtyArgs& a, int nblocks, size_t lds, hipStream_
 
 extern "C" size_t nif_xty_workspace_bytes(int64_t m, int n0, int n1, int acc, int flags) {
   if (m < 0 || n0 <= 0 || n1 <= 0) return 0;
-  const nif::XtyPlan pl = nif::make_plan(m, n0, n1, acc, flags);
-  return nif::align256(pl.slab_bytes) + nif::align256(pl.nsa_bytes) + nif::align256(pl.nsb_bytes);
+  // the plan (tile size, splits) does not depend on the input type except through the resident
+  // workgroups per CU: size for the larger of the two
+  size_t need = 0;
+  for (int in_f64 = 0; in_f64 < 2; ++in_f64) {
+    const nif::XtyPlan pl = nif::make_plan(m, n0, n1, in_f64, acc, flags);
+    const size_t b = nif::align256(pl.slab_bytes) + nif::align256(pl.nsa_bytes) + nif::align256(pl.nsb_bytes);
+    if (b > need) need = b;
+  }
+  return need;
 }
 
 extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, int n0, int n1, int in_dtype,
@@ -497,7 +623,7 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
   if ((ta || tb) && (flags & (NIF_RELU_A | NIF_RELU_B))) return NIF_ERR_UNSUPPORTED;
   if ((flags & NIF_SYMMETRIC) && (((flags & NIF_RELU_A) != 0) != ((flags & NIF_RELU_B) != 0)))
     return NIF_ERR_INVALID_ARG;
-  const XtyPlan pl = make_plan(m, n0, n1, acc, flags);
+  const XtyPlan pl = make_plan(m, n0, n1, in_dtype == NIF_F64, acc, flags);
   const size_t need = align256(pl.slab_bytes) + align256(pl.nsa_bytes) + align256(pl.nsb_bytes);
   if (!ws || ws_bytes < need) return NIF_ERR_WORKSPACE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -513,36 +639,35 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
   a.vec_b = ((reinterpret_cast<uintptr_t>(B) % 16) == 0 && ((size_t)ldb * esz_in) % 16 == 0) ? 1 : 0;
   unsigned char* w = reinterpret_cast<unsigned char*>(ws);
   a.slab = w;
-  void* nsa = w + align256(pl.slab_bytes);
-  void* nsb = w + align256(pl.slab_bytes) + align256(pl.nsa_bytes);
-  a.nslab_a = reinterpret_cast<float*>(nsa); a.nslab_b = reinterpret_cast<float*>(nsb);
-  a.dslab_a = reinterpret_cast<double*>(nsa); a.dslab_b = reinterpret_cast<double*>(nsb);
+  a.nslab_a = w + align256(pl.slab_bytes);
+  a.nslab_b = w + align256(pl.slab_bytes) + align256(pl.nsa_bytes);
 
   const int nblocks = pl.ntiles * pl.splits;
-  const size_t lds = (size_t)2 * 2 * BK * LDS_LD * esz_in;
+  size_t lds = pl.lds_bytes;
+  if (const char* pad = getenv("NIF_XTY_LDS_PAD")) lds += (size_t)atoi(pad);  // tuning aid: caps workgroups per CU
   prof_begin(NIF_PROF_XTY, st);
-  if (in_dtype == NIF_F32 && acc == NIF_F32) launch_variant<float, MmaF32>(a, nblocks, lds, st);
-  else if (in_dtype == NIF_F32) launch_variant<float, MmaF64>(a, nblocks, lds, st);
-  else launch_variant<double, MmaF64>(a, nblocks, lds, st);
+  if (in_dtype == NIF_F32 && acc == NIF_F32) {
+    if (pl.f == 3) launch_variant<float, MmaF32, 3>(a, nblocks, lds, st);
+    else launch_variant<float, MmaF32, 2>(a, nblocks, lds, st);
+  } else if (in_dtype == NIF_F32) {
+    launch_variant<float, MmaF64, 2>(a, nblocks, lds, st);
+  } else {
+    launch_variant<double, MmaF64, 2>(a, nblocks, lds, st);
+  }
   prof_end(NIF_PROF_XTY, st);
   if (!launch_ok()) return NIF_ERR_LAUNCH;
 
   const int sym = (flags & NIF_SYMMETRIC) ? 1 : 0;
-  dim3 rg((n1 + 255) / 256, n0);
+  const int nmax = n0 > n1 ? n0 : n1;
+  dim3 rg((nmax + 255) / 256, n0 + 2);
   if (acc == NIF_F32) {
-    hipLaunchKernelGGL((xty_reduce_kernel<float>), rg, dim3(256), 0, st, (const float*)a.slab, pl.splits, n0, n1,
-                       pl.n0p, pl.n1p, sym, G, ldg);
-    if (na) hipLaunchKernelGGL((xty_norm_reduce_kernel<float>), dim3((n0 + 255) / 256), dim3(256), 0, st,
-                               (const float*)nsa, pl.splits, n0, pl.n0p, na);
-    if (nb) hipLaunchKernelGGL((xty_norm_reduce_kernel<float>), dim3((n1 + 255) / 256), dim3(256), 0, st,
-                               sym ? (const float*)nsa : (const float*)nsb, pl.splits, n1, sym ? pl.n0p : pl.n1p, nb);
+    hipLaunchKernelGGL((xty_reduce_kernel<float>), rg, dim3(256), 0, st, (const float*)a.slab,
+                       (const float*)a.nslab_a, (const float*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm, sym,
+                       G, ldg, na, nb);
   } else {
-    hipLaunchKernelGGL((xty_reduce_kernel<double>), rg, dim3(256), 0, st, (const double*)a.slab, pl.splits, n0, n1,
-                       pl.n0p, pl.n1p, sym, G, ldg);
-    if (na) hipLaunchKernelGGL((xty_norm_reduce_kernel<double>), dim3((n0 + 255) / 256), dim3(256), 0, st,
-                               (const double*)nsa, pl.splits, n0, pl.n0p, na);
-    if (nb) hipLaunchKernelGGL((xty_norm_reduce_kernel<double>), dim3((n1 + 255) / 256), dim3(256), 0, st,
-                               sym ? (const double*)nsa : (const double*)nsb, pl.splits, n1, sym ? pl.n0p : pl.n1p, nb);
+    hipLaunchKernelGGL((xty_reduce_kernel<double>), rg, dim3(256), 0, st, (const double*)a.slab,
+                       (const double*)a.nslab_a, (const double*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm,
+                       sym, G, ldg, na, nb);
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
   return NIF_OK;
