@@ -1,0 +1,48 @@
+"""End-to-end fusion wall-clock on the C1 shape: random-init VGG11s, X ~ N(0,1) [B,3,32,32]."""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuron_interpolation_model_fusion_amd.models import VGG  # noqa: E402
+from neuron_interpolation_model_fusion_amd.fusion_algorithms import LSFusion, GitRebasin, OTFusion  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--algo', default='hf')
+ap.add_argument('--models', type=int, default=2)
+ap.add_argument('--batch', type=int, default=400)
+ap.add_argument('--vgg', default='VGG11')
+ap.add_argument('--verbose', action='store_true')
+a = ap.parse_args()
+dev = torch.device('cuda')
+models = []
+for k in range(a.models):
+    torch.manual_seed(100 + k)
+    models.append(VGG(a.vgg, 10, (3, 32, 32), batch_norm=False, use_bias=True, use_activations=False).eval().to(dev))
+torch.manual_seed(0)
+np.random.seed(0)
+X = torch.randn(a.batch, 3, 32, 32, device=dev)
+sink = contextlib.nullcontext() if a.verbose else contextlib.redirect_stdout(io.StringIO())
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with sink:
+        if a.algo == 'hf':
+            fused = LSFusion(models[:2]).fuse(X, None, 'hungarian')
+        elif a.algo == 'kf':
+            fused = LSFusion(models).fuse(X, None, 'k_means')
+        elif a.algo == 'gr':
+            fused = GitRebasin(models[0], models[1]).fuse(X, None, 'uniform')
+        else:
+            st = {'mode': 'acts', 'acts': {'activations_dataset': X, 'activation_labels': None,
+                                           'neuron_importance_method': 'uniform', 'normalize_activations': False}}
+            fused = OTFusion(models[:-1], models[-1]).fuse_models(st)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f'{a.algo} {a.vgg} x{a.models} B={a.batch} run {rep}: {dt:.3f} s  ({9 / dt:.2f} levels/s)', flush=True)
