@@ -57,6 +57,7 @@ from fusion_algorithms import git_rebasin as ref_gr  # noqa: E402
 from fusion_algorithms import hf_kf as ref_hf  # noqa: E402
 from models.mlp import MLPNet  # noqa: E402
 from models.vgg import VGG  # noqa: E402
+from models.vit import ViT  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -166,7 +167,7 @@ def run_kf(out, models, X):
     sd_to(out, f'kf{M}.fused', fused)
 
 
-def run_alf_kmeans(out, models, X, level_idx=0):
+def run_alf_kmeans(out, models, X, level_idx=0, align_skip=False):
     alf = ref_alf.ALFusion(models)
     nlev = len(models[0].get_ordered_trainable_named_levels)
     alf.ni_scores = [{l: torch.ones(models[k].get_ordered_trainable_named_levels[l].output_width)
@@ -177,8 +178,12 @@ def run_alf_kmeans(out, models, X, level_idx=0):
             cfg = ref_alf.ALFusionConfig(
                 X=X, y=None, optimizer_per_level=['adam'] * nlev, lr_per_level=[1e-3] * nlev,
                 weight_decay_per_level=[0.0] * nlev, epochs_per_level=[1] * nlev,
-                normalize_acts_for_kmeans=norm, init_kmeans_with_2nd_acts=init2, verbose=False)
+                normalize_acts_for_kmeans=norm, init_kmeans_with_2nd_acts=init2, verbose=False,
+                align_skip_connections=align_skip)
             level_X = X
+            if align_skip:  # the level input = previous level's output of the (un-fused) first model
+                with torch.no_grad():
+                    level_X = models[0].forward_until_level(X, level_idx - 1)
             with torch.no_grad():
                 T, assign = quiet(alf._k_means_v2, level_idx, width, cfg, level_X)
             tag = f'{int(norm)}{int(init2)}'
@@ -278,6 +283,27 @@ def fixture_vgg_tiny():
     return out
 
 
+def fixture_vit_tiny():
+    """Two narrow ViTs (reference class): ALF k-means on a transformer level [B, hidden, seq], with
+    the target/input re-alignment of skip connections (alf.py:290-294) switched on."""
+    out = {}
+    kw = dict(in_c=3, num_classes=10, img_size=16, patch=4, dropout=0.0, depth=3, hidden=16, mlp_hidden=32, head=2)
+    models = []
+    for k in range(2):
+        torch.manual_seed(400 + k)
+        models.append(ViT(**kw).eval())
+    torch.manual_seed(5)
+    X = torch.randn(12, 3, 16, 16)
+    out['X'] = X.numpy()
+    out['vit_kwargs'] = np.array([f'{a}={b}' for a, b in kw.items()])
+    for k, m in enumerate(models):
+        sd_to(out, f'sd{k}', m)
+    run_alf_kmeans(out, models, X, level_idx=1, align_skip=True)
+    meta(out)
+    np.savez_compressed(os.path.join(OUT, 'vit_tiny.npz'), **out)
+    return out
+
+
 def fixture_mlp_real():
     """The reference's own MNIST split-by-2 checkpoints (real trained weights), synthetic X."""
     out = {}
@@ -303,6 +329,6 @@ def fixture_mlp_real():
 
 
 if __name__ == '__main__':
-    for fx in (fixture_mlp_small, fixture_mlp_wide, fixture_vgg_tiny, fixture_mlp_real):
+    for fx in (fixture_mlp_small, fixture_mlp_wide, fixture_vgg_tiny, fixture_vit_tiny, fixture_mlp_real):
         o = fx()
         print(fx.__name__, len(o), 'arrays')

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from neuron_interpolation_model_fusion_amd.models import MLPNet, VGG
+from neuron_interpolation_model_fusion_amd.models import MLPNet, VGG, ViT
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -26,6 +26,9 @@ def build_models(name, z, device='cpu'):
             hid, inp = sd['level1.1.weight'].shape
             out = [v for kk, v in sd.items() if kk.startswith('level2') and kk.endswith('weight')][0].shape[0]
             m = MLPNet(inp, hid, out, use_bias=True, use_activations=False)
+        elif name.startswith('vit'):
+            kw = {a: (float(b) if a == 'dropout' else int(b)) for a, b in (e.split('=') for e in z['vit_kwargs'].tolist())}
+            m = ViT(**kw)
         else:
             cfg = [c if c == 'M' else int(c) for c in z['cfg'].tolist()]
             VGG.cfg['VGG_tiny'] = cfg

@@ -165,3 +165,27 @@ def test_alf_fuse_end_to_end_matches_reference_golden(dev):
     fused = alf.fuse(cfg)
     assert_state_close(fused, fused_state(z, 'alf'), rtol=1e-3)
     np.testing.assert_allclose(np.array(alf.weight_change_per_level), z['alf.weight_change'], rtol=1e-2)
+
+
+def test_alf_kmeans_vit_with_skip_alignment_matches_reference_golden(dev):
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusion
+    z = load_npz('vit_tiny')
+    models, X = build_models('vit_tiny', z, dev)
+    alf = ALFusion(models)
+    nlev = len(models[0].get_ordered_trainable_named_levels)
+    alf.ni_scores = [{l: torch.ones(m.get_ordered_trainable_named_levels[l].output_width) for l in range(nlev)}
+                     for m in models]
+    level = 1
+    k = models[0].get_ordered_trainable_named_levels[level].output_width
+    with torch.no_grad():
+        level_X = models[0].forward_until_level(X, level - 1)
+    for norm in (False, True):
+        for init2 in (False, True):
+            cfg = _alf_config(X, nlev, normalize_acts_for_kmeans=norm, init_kmeans_with_2nd_acts=init2,
+                              align_skip_connections=True)
+            T, assign = alf._k_means_v2(level, k, cfg, level_X)
+            tag = f'{int(norm)}{int(init2)}'
+            assert (assign.cpu().numpy() == z[f'alf.assign.{tag}']).all(), tag
+            ref = z[f'alf.T.{tag}']
+            assert T.shape == ref.shape
+            np.testing.assert_allclose(T.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())

@@ -104,3 +104,21 @@ def test_otf_oracle_properties():
     T2 = o_otf.emd(mu2, mu, C)
     assert abs(float((T1 * C).sum()) - float((T2 * C).sum())) < 1e-2
     assert torch.allclose(T2.sum(1), torch.from_numpy(mu2).float(), atol=1e-6)
+
+
+def test_alf_kmeans_oracle_vit_with_skip_alignment():
+    """Transformer level [B, hidden, seq] with the target/input re-alignment (alf.py:290-294)."""
+    z = load_npz('vit_tiny')
+    models, X = build_models('vit_tiny', z)
+    level = 1
+    k = models[0].get_ordered_trainable_named_levels[level].output_width
+    with torch.no_grad():
+        acts = [m.forward_until_level(X, level) for m in models]
+        level_X = models[0].forward_until_level(X, level - 1)
+    w = torch.ones(2 * k)
+    for norm in (False, True):
+        for init2 in (False, True):
+            T, assign = o_alf.kmeans_v2(acts, k, w, norm, init2, level_X=level_X, align_skip=True)
+            tag = f'{int(norm)}{int(init2)}'
+            assert (assign.numpy() == z[f'alf.assign.{tag}']).all(), tag
+            np.testing.assert_allclose(T.numpy(), z[f'alf.T.{tag}'], rtol=1e-5, atol=1e-6)
