@@ -207,6 +207,18 @@ int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const float* w, c
 int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const float* s0, const float* s1,
                     int n0, int d, float* out, void* stream);
 
+/* ---- ALF level fit: fused cluster-weighted squared error (alf.py:414-422 `_criterion_vectorized`,
+ * and nn.MSELoss of :434-435 when w is NULL) --------------------------------------------------------
+ * loss = mean over all elements of w[c] * (pred - truth)^2; pred / truth: [outer][C][inner] contiguous
+ * f32 (the level network's own output layout: inner = 1 for linear levels, H*W for conv, seq for
+ * transformer levels), w: C f32 or NULL.  loss: one f32 on the device.  Deterministic reduction. */
+size_t nif_wmse_workspace_bytes(void);
+int nif_wmse_forward(const float* pred, const float* truth, const float* w, int64_t outer, int C, int64_t inner,
+                     float* loss, void* ws, size_t ws_bytes, void* stream);
+/* grad_pred = grad_out[0] * 2 w[c] (pred - truth) / numel (what autograd produces for the loss above). */
+int nif_wmse_backward(const float* pred, const float* truth, const float* w, const float* grad_out, int64_t outer,
+                      int C, int64_t inner, float* grad_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,15 +10,17 @@ onto the targets with SGD/Adam (:493-594).
 Here (2) runs in Gram form: one symmetric MFMA Gram of the (per-sample-normalised) activations,
 then Lloyd steps that only stream that N x N matrix (ops.KMeans); the targets T are one
 gather-reduce pass over the activations; (3) is a cross-Gram + the device LAP kernel in scipy
-order.  (4) stays the reference's PyTorch loop: it is autograd training, not a
-kernel of this path.
+order.  (4) is autograd training and stays PyTorch, but its data path is on the device:
+batches are index gathers from resident tensors in the loader's exact sample order, and the
+(cluster-weighted) squared-error loss is one fused forward and one fused backward pass.
 """
+import math
 import time
 from dataclasses import dataclass
 
 import torch
 import torch.nn as nn
-from torch.utils.data import Dataset, DataLoader
+from torch.utils.data import Dataset
 from tqdm import trange
 
 from .. import ops
@@ -70,8 +72,66 @@ class ActivationDataset(Dataset):
         return self.X[idx], self.T[idx]
 
 
+class _GraphedBatch:
+    """Forward + loss (+ backward) of one full-size batch of a level fit, captured once in a HIP graph and
+    replayed per batch: the fit of a narrow level is launch-bound (a few dozen small kernels per step).
+    The optimiser step stays outside the graph, so Adam / SGD behave exactly as in eager mode.  The first
+    ``warmup`` full batches run eagerly (library handles, kernel selection) before the capture."""
+
+    def __init__(self, level_X, T, batch_size, train, warmup=2):
+        self.x = torch.empty((batch_size,) + tuple(level_X.shape[1:]), dtype=level_X.dtype, device=level_X.device)
+        self.y = torch.empty((batch_size,) + tuple(T.shape[1:]), dtype=T.dtype, device=T.device)
+        self.loss = torch.zeros((), dtype=torch.float64, device=level_X.device)
+        self.train = train
+        self.warmup = warmup
+        self.graph = None
+        self.failed = False
+        self.params, self.grads = [], []
+
+    def ready(self, host, network, criterion):
+        if self.failed:
+            return False
+        if self.graph is not None:
+            return True
+        if self.warmup > 0:
+            self.warmup -= 1
+            return False
+        try:
+            self._capture(host, network, criterion)
+        except RuntimeError as e:  # e.g. a level whose forward synchronises: keep the eager loop
+            print(f'[ALFusion] HIP graph capture of the level fit failed, continuing eagerly: {e}')
+            self.graph, self.failed = None, True
+        return self.graph is not None
+
+    def _capture(self, host, network, criterion):
+        self.params = [p for p in network.parameters() if p.requires_grad]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            if self.train:
+                for p in self.params:
+                    p.grad = None
+                loss = host._batch_loss(network, criterion, self.x, self.y)
+                loss.backward()
+            else:
+                with torch.no_grad():
+                    loss = host._batch_loss(network, criterion, self.x, self.y)
+            self.loss.copy_(loss.detach().double())
+        self.grads = [p.grad for p in self.params]
+        self.graph = graph
+
+    def replay(self, level_X, T, idx, total):
+        torch.index_select(level_X, 0, idx, out=self.x)
+        torch.index_select(T, 0, idx, out=self.y)
+        self.graph.replay()
+        if self.train:
+            for p, g in zip(self.params, self.grads):
+                p.grad = g  # an eager batch in between re-pointed .grad; the graph writes to these
+        total += self.loss
+
+
 class ALFusion:
     neuron_importance_methods = ['uniform', 'conductance', 'deeplift', 'featureablation']
+    use_hip_graphs = True  # replay the per-batch forward/backward of the level fit as a HIP graph
 
     def __init__(self, models):
         self.models = models
@@ -235,11 +295,18 @@ class ALFusion:
         return T, assignment
 
     def _criterion_vectorized(self, act_pred, act_true, cluster_weights):
-        return (((act_pred - act_true) ** 2) * cluster_weights).mean()
+        """mean(cluster_weights[c] * (pred - true)^2) (alf.py:414-422), one fused pass on the device."""
+        return ops.weighted_mse(act_pred, act_true, cluster_weights)
 
     def _get_criterion(self, level_idx, target_width, assignment, fusion_config, is_last_level):
+        """alf.py:424-454.  The squared-error criteria accept the level's own [batch, channel, ...] layout as
+        well as the flattened (rows, channel) one (the mean runs over every element either way) and are
+        tagged ``native_layout`` so the fit loop skips the flatten copies."""
         if not fusion_config.use_weighted_loss or (is_last_level and fusion_config.cls_head_weights is None):
-            return nn.MSELoss().to(self.device)
+            def mse_loss(y_pred, y_true):
+                return ops.weighted_mse(y_pred, y_true, None)
+            mse_loss.native_layout = True
+            return mse_loss
         if is_last_level and fusion_config.use_kd_on_head:
             return nn.KLDivLoss(reduction='batchmean').to(self.device)
         ni_scores = torch.cat([self.ni_scores[i][level_idx] for i in range(len(self.models))], dim=0)
@@ -249,6 +316,7 @@ class ALFusion:
 
         def weighted_loss(y_pred, y_true):
             return self._criterion_vectorized(y_pred, y_true, cluster_weights)
+        weighted_loss.native_layout = True
         return weighted_loss
 
     def _get_optimizer(self, level_idx, level_network, fusion_config):
@@ -270,7 +338,61 @@ class ALFusion:
         with torch.no_grad():
             return fused_hat.forward_until_level(fusion_config.X, level_idx - 1)
 
-    # -- per-level fit (alf.py:493-594): the reference's training loop, unchanged in behaviour ---------------
+    # -- per-level fit (alf.py:493-594) ------------------------------------------------------------------
+    @staticmethod
+    def _split_indices(n):
+        """Index sets of ``random_split(dataset, [0.8, 0.2])`` (alf.py:518): same lengths, same single
+        ``randperm`` draw from the default CPU generator, without materialising per-sample datasets."""
+        lengths = [int(math.floor(n * f)) for f in (0.8, 0.2)]
+        for i in range(n - sum(lengths)):
+            lengths[i % 2] += 1
+        perm = torch.randperm(n)
+        return perm[:lengths[0]], perm[lengths[0]:]
+
+    @staticmethod
+    def _loader_order(n, shuffle):
+        """Sample order of one pass of ``DataLoader(..., shuffle=shuffle)`` (alf.py:519-520), consuming the
+        default generator exactly as the loader does: one draw per iterator, and for a shuffled pass one
+        more that seeds the private generator of the permutation."""
+        torch.empty((), dtype=torch.int64).random_()
+        if not shuffle:
+            return torch.arange(n)
+        g = torch.Generator()
+        g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        return torch.randperm(n, generator=g)
+
+    def _batch_loss(self, network, criterion, x, y):
+        y_hat = network(x)
+        if not getattr(criterion, 'native_layout', False):
+            y_hat, y = self._flatten_acts(y_hat), self._flatten_acts(y)
+        return criterion(y_hat, y)
+
+    def _run_batches(self, network, criterion, level_X, T, order, batch_size, optimizer=None, graphed=None):
+        """One pass over ``order`` in batches sliced on the device; returns (sum of batch losses, batches).
+        The losses are accumulated on the device in f64 (the order and values the reference's running
+        Python float sum sees) and read back once.  ``graphed`` (a _GraphedBatch) replays full-size batches
+        as one HIP graph launch each; ragged tails and the warm-up batches run eagerly."""
+        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        num_batches = 0
+        for lo in range(0, order.shape[0], batch_size):
+            idx = order[lo:lo + batch_size]
+            if graphed is not None and idx.shape[0] == batch_size and graphed.ready(self, network, criterion):
+                graphed.replay(level_X, T, idx, total)
+                if optimizer is not None:
+                    optimizer.step()
+            else:
+                x, y = level_X.index_select(0, idx), T.index_select(0, idx)
+                if optimizer is not None:
+                    optimizer.zero_grad()
+                loss = self._batch_loss(network, criterion, x, y)
+                if optimizer is not None:
+                    loss.backward()
+                    optimizer.step()
+                total += loss.detach().double()
+                del loss  # a live autograd graph would pin its AccumulateGrad nodes to this stream and break a later capture
+            num_batches += 1
+        return total.item(), num_batches
+
     def _fuse_level_sgd(self, level_idx, fused_hat, fusion_config):
         level_X = self._get_level_input(level_idx, fused_hat, fusion_config)
         level = fused_hat.get_ordered_trainable_named_levels[level_idx]
@@ -284,10 +406,13 @@ class ALFusion:
         else:
             T, assignment = self._last_level_grouping(target_width, fusion_config)
 
-        dataset = ActivationDataset(level_X, T)
-        train_dataset, val_dataset = torch.utils.data.random_split(dataset, [0.8, 0.2])
-        train_dl = DataLoader(train_dataset, batch_size=fusion_config.train_batch_size, shuffle=True)
-        val_dl = DataLoader(val_dataset, batch_size=fusion_config.train_batch_size, shuffle=False)
+        # inputs and targets stay resident on the device in the network's own layout; batches are index
+        # gathers (the reference builds per-sample Dataset / DataLoader objects over the same tensors)
+        level_X = level_X.to(self.device).float().contiguous()
+        T = T.to(self.device).float().contiguous()
+        train_idx, val_idx = self._split_indices(level_X.shape[0])
+        val_order = val_idx.to(self.device)
+        batch_size = fusion_config.train_batch_size
 
         if level_idx in (fusion_config.reset_level_parameters or []):
             reset_parameters(network)
@@ -301,30 +426,31 @@ class ALFusion:
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=50)
         criterion = self._get_criterion(level_idx, target_width, assignment, fusion_config, is_last_level)
 
+        # launch-bound inner loop -> one HIP graph per phase once a level has enough full batches to pay for it
+        use_graphs = self.use_hip_graphs and level_X.is_cuda
+        train_graph = _GraphedBatch(level_X, T, batch_size, True) \
+            if use_graphs and train_idx.shape[0] // batch_size >= 8 else None
+        val_graph = _GraphedBatch(level_X, T, batch_size, False) \
+            if use_graphs and val_idx.shape[0] // batch_size >= 8 else None
+
         patience = fusion_config.max_patience_epochs
         best_val_loss = float('inf')
         num_epochs = fusion_config.epochs_per_level[level_idx]
         for epoch in range(num_epochs):
-            train_loss = 0.0
             network.train(True)
-            for x, y in train_dl:
-                x, y = x.to(self.device).float(), self._flatten_acts(y).to(self.device).float()
-                optimizer.zero_grad()
-                loss = criterion(self._flatten_acts(network(x)), y)
-                loss.backward()
-                train_loss += loss.item()
-                optimizer.step()
+            train_order = train_idx[self._loader_order(train_idx.shape[0], True)].to(self.device)
+            train_loss, train_batches = self._run_batches(network, criterion, level_X, T, train_order, batch_size,
+                                                          optimizer, train_graph)
             if fusion_config.use_scheduler:
                 scheduler.step(train_loss)  # the reference passes the loss as the epoch argument (alf.py:559)
 
-            val_loss = 0.0
             network.eval()
+            self._loader_order(val_idx.shape[0], False)
             with torch.no_grad():
-                for x, y in val_dl:
-                    x, y = x.to(self.device).float(), self._flatten_acts(y).to(self.device).float()
-                    val_loss += criterion(self._flatten_acts(network(x)), y).item()
-            avg_train_loss = train_loss / len(train_dl)
-            avg_val_loss = val_loss / len(val_dl)
+                val_loss, val_batches = self._run_batches(network, criterion, level_X, T, val_order, batch_size,
+                                                          None, val_graph)
+            avg_train_loss = train_loss / train_batches
+            avg_val_loss = val_loss / val_batches
             if fusion_config.verbose:
                 print(f'Epoch: {epoch + 1}/{num_epochs}.    Avg Train Loss: {avg_train_loss:.4f}.    '
                       f'Avg Val Loss: {avg_val_loss:.4f}.')
@@ -338,6 +464,8 @@ class ALFusion:
                 best_val_loss = avg_val_loss
                 patience = fusion_config.max_patience_epochs
 
+        if train_graph is not None and train_graph.graph is not None:
+            optimizer.zero_grad(set_to_none=True)  # the gradients lived in the graph's private pool
         weights_after = nn.utils.parameters_to_vector(network.parameters()).detach().clone()
         weight_change = torch.norm(weights_after - weights_before).item()
         self.weight_change_per_level.append(weight_change)

@@ -339,3 +339,55 @@ class KMeans:
                                          self.k, _ptr(kprime), _ptr(self.ws), self.nbytes, _stream()),
                   'nif_kmeans_targets')
         return T, kprime
+
+
+# ---- fused loss of the ALF level fit -----------------------------------------------------------------
+
+def _loss_dims(t):
+    if t.dim() < 2:
+        raise ValueError(f'weighted_mse expects [batch, channels, ...], got shape {tuple(t.shape)}')
+    inner = 1
+    for s in t.shape[2:]:
+        inner *= s
+    return t.shape[0], t.shape[1], inner
+
+
+class _WeightedMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, truth, w):
+        outer, C, inner = _loss_dims(pred)
+        dev = pred.device
+        with torch.cuda.device(dev):
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            wsz = lib.nif_wmse_workspace_bytes()
+            ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+            check(lib.nif_wmse_forward(_ptr(pred), _ptr(truth), _ptr(w), outer, C, inner, _ptr(loss), _ptr(ws), wsz,
+                                       _stream()), 'nif_wmse_forward')
+        ctx.save_for_backward(pred, truth, w)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pred, truth, w = ctx.saved_tensors
+        outer, C, inner = _loss_dims(pred)
+        grad_out = grad_out.to(torch.float32).contiguous()
+        with torch.cuda.device(pred.device):
+            grad = torch.empty_like(pred)
+            check(lib.nif_wmse_backward(_ptr(pred), _ptr(truth), _ptr(w), _ptr(grad_out), outer, C, inner, _ptr(grad),
+                                        _stream()), 'nif_wmse_backward')
+        return grad, None, None
+
+
+def weighted_mse(pred, truth, w=None):
+    """mean(w[c] * (pred - truth)^2) over every element, c = index along dim 1 (alf.py:414-422); plain
+    MSE when w is None.  pred / truth: [batch, channels, ...] f32; differentiable w.r.t. pred."""
+    _need_gpu(pred, truth, w)
+    if pred.shape != truth.shape:
+        raise ValueError(f'shape mismatch: {tuple(pred.shape)} vs {tuple(truth.shape)}')
+    pred = pred.float().contiguous()
+    truth = truth.detach().float().contiguous()
+    if w is not None:
+        w = w.detach().to(device=pred.device, dtype=torch.float32).contiguous()
+        if w.numel() != pred.shape[1]:
+            raise ValueError(f'w has {w.numel()} entries for {pred.shape[1]} channels')
+    return _WeightedMSE.apply(pred, truth, w)

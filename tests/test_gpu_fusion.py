@@ -189,3 +189,48 @@ def test_alf_kmeans_vit_with_skip_alignment_matches_reference_golden(dev):
             ref = z[f'alf.T.{tag}']
             assert T.shape == ref.shape
             np.testing.assert_allclose(T.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('arch', ['mlp', 'vgg_bn', 'vit'])
+def test_alf_fit_with_hip_graph_replay_equals_eager_loop(dev, arch):
+    """The graph-replayed level fit (full batches as one graph launch, ragged tail eager) must walk the same
+    trajectory as the eager loop: same batches, same kernels, so the fused weights agree to rounding."""
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusion
+    from neuron_interpolation_model_fusion_amd.models import MLPNet, VGG, ViT
+    torch.manual_seed(3)
+    if arch == 'mlp':
+        make = lambda: MLPNet(64, 48, 10, use_bias=True, use_activations=False)
+        X = torch.randn(1615, 64)
+    elif arch == 'vgg_bn':
+        VGG.cfg.setdefault('VGG_graph_test', [8, 'M', 16, 'M'])
+        make = lambda: VGG('VGG_graph_test', 10, (3, 8, 8), batch_norm=True, use_bias=True, use_activations=False)
+        X = torch.randn(815, 3, 8, 8)
+    else:
+        make = lambda: ViT(in_c=3, num_classes=10, img_size=8, patch=4, depth=1, hidden=16, mlp_hidden=32, head=2)
+        X = torch.randn(815, 3, 8, 8)
+    models = [make().to(dev) for _ in range(2)]
+    X = X.to(dev)
+    nlev = len(models[0].get_ordered_trainable_named_levels)
+    results = []
+    for graphs in (False, True):
+        # a conv bias in front of BatchNorm has zero true gradient; Adam would turn its rounding noise into
+        # lr-sized steps, so that architecture is fitted with SGD
+        optim, lr = ('sgd', 1e-2) if arch == 'vgg_bn' else ('adam', 1e-3)
+        cfg = _alf_config(X, nlev, optimizer_per_level=[optim] * nlev, lr_per_level=[lr] * nlev,
+                          epochs_per_level=[2] * nlev, train_batch_size=16, use_scheduler=True)
+        copies = [m.copy_model() for m in models]
+        torch.manual_seed(11)
+        np.random.seed(11)
+        alf = ALFusion(copies)
+        alf.use_hip_graphs = graphs
+        fused = alf.fuse(cfg)
+        results.append(({k: v.detach().cpu() for k, v in fused.state_dict().items()}, alf.weight_change_per_level))
+    (eager, wc_e), (graphed, wc_g) = results
+    assert eager.keys() == graphed.keys()
+    for k in eager:
+        if eager[k].dtype.is_floating_point:
+            scale = float(eager[k].abs().max()) + 1e-12
+            np.testing.assert_allclose(graphed[k].numpy(), eager[k].numpy(), rtol=1e-4, atol=1e-5 * scale, err_msg=k)
+        else:
+            assert torch.equal(eager[k], graphed[k]), k
+    np.testing.assert_allclose(wc_g, wc_e, rtol=1e-4)

@@ -192,3 +192,32 @@ def test_lap_scipy_order_reproduces_scipy_under_ties(ops, n):
     for Cx in cases:
         col, ref = _check_lap(ops, Cx, scipy_order=True)
         assert (col == ref).all()
+
+
+@pytest.mark.parametrize('shape', [(37, 10), (5, 7, 3, 3), (4, 16, 17), (64, 384, 65), (256, 64, 8, 8), (1, 1)])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_weighted_mse_forward_and_gradient(ops, shape, weighted):
+    """Fused loss of the ALF fit against the reference's expression (alf.py:420-421) under autograd, in f64."""
+    g = torch.Generator().manual_seed(sum(shape))
+    pred = torch.randn(*shape, generator=g)
+    truth = torch.randn(*shape, generator=g)
+    w = (torch.rand(shape[1], generator=g) + 0.1) if weighted else None
+
+    p64 = pred.double().requires_grad_(True)
+    wb = torch.ones(shape[1], dtype=torch.float64) if w is None else w.double()
+    wb = wb.reshape([1, -1] + [1] * (len(shape) - 2))
+    ref = (((p64 - truth.double()) ** 2) * wb).mean()
+    (ref * 3.0).backward()
+
+    pg = pred.cuda().requires_grad_(True)
+    loss = ops.weighted_mse(pg, truth.cuda(), None if w is None else w.cuda())
+    (loss * 3.0).backward()
+    assert loss.dtype == torch.float32 and loss.dim() == 0
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), p64.grad.float().numpy(), rtol=2e-6, atol=1e-9)
+    # the flattened (rows, channels) view the reference feeds its criterion gives the same value
+    if len(shape) > 2:
+        flat = pred.movedim(1, -1).reshape(-1, shape[1]).contiguous().cuda()
+        flat_t = truth.movedim(1, -1).reshape(-1, shape[1]).contiguous().cuda()
+        loss_flat = ops.weighted_mse(flat, flat_t, None if w is None else w.cuda())
+        np.testing.assert_allclose(loss_flat.item(), ref.item(), rtol=2e-6)
