@@ -33,3 +33,51 @@ def test_on_device_batching_visits_samples_in_the_loaders_order():
         for r, g in zip(ref, got):
             assert torch.equal(r, g)
         assert torch.equal(ref_tail, tail)
+
+
+def test_eval_model_metrics_on_a_known_classifier():
+    from neuron_interpolation_model_fusion_amd.utils.run_utils import eval_model
+    torch.manual_seed(0)
+    n, c = 200, 4
+    y = torch.arange(n) % c
+    logits = torch.nn.functional.one_hot(y, c).float() * 4 + torch.randn(n, c)
+
+    class Fixed(torch.nn.Module):
+        def forward(self, idx):
+            return logits[idx.long().reshape(-1)]
+    batches = [(torch.arange(i, min(i + 32, n)), y[i:i + 32]) for i in range(0, n, 32)]
+    stats = eval_model(Fixed(), batches, device='cpu', num_classes=c)
+    pred = logits.argmax(1)
+    assert abs(stats['accuracy'] - float((pred == y).double().mean())) < 1e-12
+    cm = stats['confusion_matrix']
+    assert cm.sum() == n and int(cm.diag().sum()) == int((pred == y).sum())
+    for t in range(c):
+        for p in range(c):
+            assert int(cm[t, p]) == int(((y == t) & (pred == p)).sum())
+    assert abs(stats['loss'] - torch.nn.functional.cross_entropy(logits, y).item()) < 1e-6
+    assert 0.5 < stats['roc_auc'] <= 1.0 and 0.0 < stats['f1'] <= 1.0
+
+
+REF_CKPT = '/root/reference/example-base-models/non-iid/MLPs/MNIST/split-by-2/seed1'
+
+
+def test_reference_whole_module_checkpoints_load_into_our_classes(tmp_path):
+    """Data files of the reference (safe loader only); skipped where the reference tree is absent."""
+    import os
+    import pytest
+    if not os.path.isdir(REF_CKPT):
+        pytest.skip('reference checkpoints not present on this machine')
+    from neuron_interpolation_model_fusion_amd.models import MLPNet
+    from neuron_interpolation_model_fusion_amd.utils.run_utils import load_model
+    from tests.helpers import load_npz
+    m = load_model(os.path.join(REF_CKPT, 'model_0.pt'))
+    assert type(m) is MLPNet and (m.input_size, m.hidden_size, m.output_size) == (784, 256, 10)
+    z = load_npz('mlp_real')  # the same checkpoint's weights as minted into the golden fixture
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, torch.from_numpy(z[f'sd0.{k}'])), k
+    assert len(m.train_indices) > 0
+    assert m(torch.zeros(2, 1, 28, 28)).shape == (2, 10)
+    # a model saved from here loads back through the same allow-list
+    torch.save(m.copy_model(), tmp_path / 'again.pt')
+    again = load_model(tmp_path / 'again.pt')
+    assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), m.state_dict().values()))
