@@ -64,18 +64,20 @@ def get_preactivations_of_layer(model, target_model, layer):
 
 
 def compute_neuron_importance_scores(method, model, idx, X, y, fusion_logic, batch_size=50):
-    """Per-neuron importance of a layer or level, on the CPU (fusion_utils.py:85-111).
+    """Per-neuron importance of a layer or level, returned on the CPU (fusion_utils.py:85-111).
 
-    Only 'uniform' is built: conductance / deeplift / featureablation are captum
-    attributions (utils/neuron_importance.py), outside the hot path.
+    'uniform' is ``ones(width)``; 'conductance' / 'deeplift' / anything else (feature ablation, as in the
+    reference's final ``else``) are the attributions restated in utils/neuron_importance.py.
     """
     assert fusion_logic in ['layer', 'level'], f'Invalid fusion logic: {fusion_logic}'
     if fusion_logic == 'layer':
+        layer = model.get_ordered_trainable_named_layers[idx].layer
         width = get_layer_width(model, idx)
     else:
-        width = model.get_ordered_trainable_named_levels[idx].output_width
+        level = model.get_ordered_trainable_named_levels[idx]
+        layer, width = level.network, level.output_width
     if method == 'uniform':
         return torch.ones(width)
-    raise NotImplementedError(
-        f"neuron importance method '{method}' needs captum attributions (reference utils/neuron_importance.py); "
-        "only 'uniform' is available in this build")
+    from .neuron_importance import get_score
+    name = method if method in ('conductance', 'deeplift') else 'featureablation'
+    return get_score(name, model, layer, width, X, y, batch_size=batch_size).cpu()

@@ -234,3 +234,41 @@ def test_alf_fit_with_hip_graph_replay_equals_eager_loop(dev, arch):
         else:
             assert torch.equal(eager[k], graphed[k]), k
     np.testing.assert_allclose(wc_g, wc_e, rtol=1e-4)
+
+
+@pytest.mark.parametrize('name,method', [('mlp_small', 'conductance'), ('vgg_tiny', 'deeplift')])
+def test_non_uniform_importance_flows_through_hf_kf_gr_like_the_oracle(dev, name, method):
+    """Attribution scores (captum-free restatement; their own parity is unpinned) computed on the device
+    models, then HF / KF / GR on the HIP path against the oracle driven with the very same scores."""
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import LSFusion, GitRebasin
+    from neuron_interpolation_model_fusion_amd.utils.fusion_utils import compute_neuron_importance_scores
+    from oracle import hf_kf as o_ls, git_rebasin as o_gr
+    z = load_npz(name)
+    models, X = build_models(name, z, dev)
+    models = models[:2]
+    cpu_models, X_cpu = build_models(name, z)
+    cpu_models = cpu_models[:2]
+    y = (torch.arange(X.shape[0]) % 10).to(dev)
+
+    ls = LSFusion(models)
+    fused = ls.fuse(X, y, fusion_method='hungarian', neuron_importance_method=method, norm_neuron_importance=True)
+    scores = [[s.clone() for s in per] for per in ls.neuron_importance_scores]
+    assert all(s.min() > 0 and (s.max() / s.min()) > 1.5 for per in scores for s in per[:-1]), 'scores are non-trivial'
+    log = []
+    ref = o_ls.ls_fuse(cpu_models, X_cpu, 'hungarian', scores=scores, log=log)
+    for l, info in enumerate(ls.last_layer_info[:-1]):  # the output layer's solve is discarded (identity, hf_kf.py:254-255)
+        assert (info['col'].cpu().numpy() == log[l]['col']).all(), f'HF layer {l}'
+    assert_state_close(fused, dict(ref.state_dict()), rtol=1e-3)
+
+    np.random.seed(7)
+    fused = LSFusion(models).fuse(X, y, fusion_method='k_means', neuron_importance_method=method)
+    np.random.seed(7)
+    ref = o_ls.ls_fuse(cpu_models, X_cpu, 'k_means', scores=scores)
+    assert_state_close(fused, dict(ref.state_dict()), rtol=1e-3)
+
+    gr = GitRebasin(models[0], models[1])
+    fused = gr.fuse(X, y, method)
+    n_layers = len(scores[0])
+    raw = [[compute_neuron_importance_scores(method, m, l, X, y, 'layer') for l in range(n_layers)] for m in models]
+    ref = o_gr.gr_fuse(cpu_models[0], cpu_models[1], X_cpu, raw[0], raw[1])
+    assert_state_close(fused, dict(ref.state_dict()), rtol=1e-3)
