@@ -207,6 +207,30 @@ int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const float* w, c
 int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const float* s0, const float* s1,
                     int n0, int d, float* out, void* stream);
 
+/* ---- exact optimal transport with arbitrary marginals (POT `ot.emd`, otfusion.py:18-32, call site :309) ----
+ * min <T, C> s.t. T 1 = a, T^T 1 = b, T >= 0 for a dense n0 x n1 f32 cost (>= 0) and f64 marginals with equal
+ * sums (POT rescales b to a's total; the caller does the same).  Successive shortest augmenting paths, f64
+ * duals, one workgroup.  The plan comes back sparse, by column: colptr[n1 + 1], rowidx / val[<= out_cap]
+ * (a vertex of the transport polytope has at most n0 + n1 - 1 positive entries).  status[0] (device) = number
+ * of entries, or a negative NIF_ERR_*.  tol: flows / supplies below it count as zero (e.g. 1e-13 * sum a).
+ * u / v (optional): optimal duals, u_i + v_j <= C_ij with equality on the support.  Uniform square problems
+ * are assignments: use nif_lap_solve_f32 for those. */
+#define NIF_EMD_MAX_N 8192
+size_t nif_emd_workspace_bytes(int n0, int n1);
+int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, const double* a, const double* b, double tol,
+                      int32_t* colptr, int32_t* rowidx, double* val, int32_t out_cap, int32_t* status, double* u,
+                      double* v, void* ws, size_t ws_bytes, void* stream);
+
+/* OTFusion alignment with general (sparse) plans, otfusion.py:261-335:
+ * out[j][q*sp + s] = beta * W0[j][q*sp + s]
+ *                  + alpha * sum_{e in col j of R} rv[e] * sum_{f in col q of P} cv[f] * W1[ri[e]][ci[f]*sp + s]
+ * R = T^T diag(1/mu) of the current layer and P = T_prev diag(1/nu_prev), both handed over as CSC triplets of T
+ * with the scaling folded into the values; a NULL triplet is the identity.  W1: n_k x ldw1, out / W0:
+ * n_out x (n_in * sp) contiguous, W0 may be NULL (then beta is ignored). */
+int nif_refit_sparse(const float* W0, const float* W1, int64_t ldw1, const int32_t* rptr, const int32_t* ri,
+                     const float* rv, const int32_t* cptr, const int32_t* ci, const float* cv, float alpha, float beta,
+                     int n_out, int n_in, int sp, float* out, void* stream);
+
 /* ---- ALF level fit: fused cluster-weighted squared error (alf.py:414-422 `_criterion_vectorized`,
  * and nn.MSELoss of :434-435 when w is NULL) --------------------------------------------------------
  * loss = mean over all elements of w[c] * (pred - truth)^2; pred / truth: [outer][C][inner] contiguous

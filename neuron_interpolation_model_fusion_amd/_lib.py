@@ -45,6 +45,11 @@ SIGNATURES = {
     'nif_kmeans_targets': (_i32, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     'nif_refit_pairs': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     'nif_refit_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32, _vp, _vp]),
+    'nif_emd_workspace_bytes': (_sz, [_i32, _i32]),
+    'nif_emd_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _c.c_double, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+                                 _sz, _vp]),
+    'nif_refit_sparse': (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32,
+                                _vp, _vp]),
     'nif_wmse_workspace_bytes': (_sz, []),
     'nif_wmse_forward': (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _sz, _vp]),
     'nif_wmse_backward': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),

@@ -3,19 +3,19 @@
 Same class and ``fuse_models`` signature / alignment_strategy schema (run_otf.py:100-109).
 The reference computes the ground metric with torch.cdist on the CPU (otfusion.py:150) and the
 plan with POT's network simplex ``ot.emd`` on the CPU (:32).  With uniform marginals on a
-square problem -- the only case 'uniform' importance produces for equal-width models
-(:242,258) -- an optimal plan is a vertex P/n of the Birkhoff polytope, so the exact plan comes
-from the device assignment kernel; plans stay index vectors and the two T-matrix products of a
-layer (edge alignment :261-306, barycentric projection :313-335) collapse into one gather fused
-with the running sum.  Non-uniform or rectangular problems need a general transport solve,
-which this build does not carry (it raises instead of approximating).
+square problem -- what 'uniform' importance produces for equal-width models (:242,258) -- an
+optimal plan is a vertex P/n of the Birkhoff polytope, so the exact plan comes from the device
+assignment kernel; plans stay index vectors and the two T-matrix products of a layer (edge
+alignment :261-306, barycentric projection :313-335) collapse into one gather fused with the
+running sum.  Non-uniform importances or unequal widths go through the exact transport kernel
+(nif_emd_solve_f32); its plans have at most n_k + n_f - 1 entries and stay sparse, and the same
+two products become one sparse gather (nif_refit_sparse).
 """
 import time
 
 import torch
 
 from .. import ops
-from .._lib import NifError
 from ..utils.fusion_utils import (
     get_num_layers, initialize_activations, get_layer_weight, get_layer_width, get_preactivations_of_layer,
     compute_neuron_importance_scores)
@@ -24,22 +24,26 @@ from ..utils.model_utils import is_conv_weight
 
 def get_ot_matrix(cost, mu, nu):
     """Exact OT plan for a device cost matrix (dim1, dim2) with marginals mu, nu (otfusion.py:18-32).
-    Returns the dense plan T (device, f32).  Uniform square problems only."""
-    row4col = _uniform_plan(cost, mu, nu)
-    n = cost.shape[0]
-    T = torch.zeros(n, n, device=cost.device)
-    T[row4col.long(), torch.arange(n, device=cost.device)] = 1.0 / n
-    return T
+    Returns the dense plan T (device, f32)."""
+    perm, plan = _solve_plan(cost, mu, nu)
+    if plan is None:
+        plan = ops.SparsePlan.from_permutation(perm, float(mu[0]))
+    return plan.dense()
 
 
-def _uniform_plan(cost, mu, nu):
+def _solve_plan(cost, mu, nu):
+    """(row4col, None) when the problem is an assignment (uniform marginals, equal widths: T = P / n),
+    else (None, SparsePlan) from the exact transport kernel."""
     n0, n1 = cost.shape
-    uniform = bool(torch.allclose(mu, mu[:1].expand_as(mu)) and torch.allclose(nu, nu[:1].expand_as(nu)))
-    if n0 != n1 or not uniform:
-        raise NifError('OTFusion: only uniform marginals on equal widths are covered (exact plan = permutation / n); '
-                       'a general exact transport solve (ot.emd, otfusion.py:32) is not part of this build')
-    _, row4col, _, _ = ops.lap_solve(cost, duals=True)
-    return row4col
+    uniform = n0 == n1 and bool(torch.equal(mu, mu[:1].expand_as(mu)) and torch.equal(nu, nu[:1].expand_as(nu)))
+    if uniform:
+        _, row4col, _, _ = ops.lap_solve(cost, duals=True)
+        return row4col, None
+    return None, ops.emd_solve(cost, mu, nu)
+
+
+def _as_sparse(perm, plan, value):
+    return plan if plan is not None else ops.SparsePlan.from_permutation(perm, value)
 
 
 class OTFusion:
@@ -143,9 +147,12 @@ class OTFusion:
         if mode == 'acts':
             self._initialize_activations(fused_hat)  # target activations are captured once (otfusion.py:223-224)
 
-        # plans as index vectors: row4col_prev[k][j'] = model-k unit transported to fused unit j' of the
-        # previous layer; None = the identity coupling diag(nu_prev) of the input (otfusion.py:216-217)
-        prev_plan = [None for _ in self.models]
+        # plans of the previous layer per model, as (row4col, None) -- row4col[j'] = model-k unit transported
+        # to fused unit j' -- or (None, SparsePlan); (None, None) = the identity coupling diag(nu_prev) of the
+        # input (otfusion.py:216-217)
+        prev_plan = [(None, None) for _ in self.models]
+        prev_width = [input_dim for _ in self.models]
+        nu_prev = None
         prev_is_conv = False
         self.plans = []
         for layer in range(num_layers):
@@ -182,36 +189,53 @@ class OTFusion:
                 if is_conv:
                     sp = model_k_weight.shape[2]
                 elif prev_is_conv:
-                    sp = model_k_weight.shape[1] // prev_plan[k].shape[0]
+                    sp = model_k_weight.shape[1] // prev_width[k]
                 else:
                     sp = 1
                 wk_flat = model_k_weight.reshape(n_k, -1).contiguous()
+                p_perm, p_sparse = prev_plan[k]
+                # column side of the alignment, T_prev diag(1/nu_prev): an index vector, or a CSC triplet
+                cols = p_sparse.scaled(col_scale=1.0 / nu_prev) if p_sparse is not None else None
 
                 # ground metric; 'wts' mode needs the edge-aligned weight W_k T_prev diag(1/nu_prev) first
                 if mode == 'acts':
                     C = self._get_ground_metric(model, fused_hat, layer, None)
                 else:
-                    edges = ops.refit_gather(None, wk_flat, colsrc=prev_plan[k], alpha=0.0, beta=1.0, sp=sp)
+                    if cols is None:
+                        edges = ops.refit_gather(None, wk_flat, colsrc=p_perm, alpha=0.0, beta=1.0, sp=sp)
+                    else:
+                        edges = ops.refit_sparse(None, wk_flat, cols=cols, sp=sp)
                     C = self._get_ground_metric(model, fused_hat, layer, edges)
-                row4col = _uniform_plan(C, mu, nu)
-                plan = row4col
-                self.plans.append((layer, k, row4col))
-                if layer == num_layers - 1:
-                    row4col = torch.arange(n_k, device=dev, dtype=torch.int32)  # T_corrected = I (otfusion.py:315-316)
-
-                # total += T^T diag(1/mu) (W_k T_prev diag(1/nu_prev)): one gather, accumulated in place
-                total_weight = ops.refit_gather(total_weight, wk_flat, rowsrc=row4col, colsrc=prev_plan[k],
-                                                alpha=1.0, beta=1.0, sp=sp)
+                perm, sparse = _solve_plan(C, mu, nu)
+                self.plans.append((layer, k, perm if sparse is None else sparse))
+                last = layer == num_layers - 1  # T_corrected = I on the output layer (otfusion.py:315-316)
                 if handle_bias:
                     bk = model.get_ordered_trainable_named_layers[layer].layer.bias.detach().reshape(n_k, 1).to(dev)
-                    total_bias = ops.refit_gather(total_bias, bk, rowsrc=row4col, alpha=1.0, beta=1.0)
-                prev_plan[k] = plan
+
+                # total += T^T diag(1/mu) (W_k T_prev diag(1/nu_prev)), accumulated in place by one gather:
+                # index vectors when both plans are permutations, the sparse form otherwise
+                if (last or sparse is None) and cols is None:
+                    rowsrc = torch.arange(n_k, device=dev, dtype=torch.int32) if last else perm
+                    total_weight = ops.refit_gather(total_weight, wk_flat, rowsrc=rowsrc, colsrc=p_perm,
+                                                    alpha=1.0, beta=1.0, sp=sp)
+                    if handle_bias:
+                        total_bias = ops.refit_gather(total_bias, bk, rowsrc=rowsrc, alpha=1.0, beta=1.0)
+                else:
+                    rows = None if last else _as_sparse(perm, sparse, float(mu[0])).scaled(row_scale=1.0 / mu)
+                    if cols is None and p_perm is not None:
+                        cols = _as_sparse(p_perm, None, 1.0).scaled()  # P diag(1/nu_prev) of a permutation plan = P
+                    total_weight = ops.refit_sparse(total_weight, wk_flat, rows=rows, cols=cols, sp=sp)
+                    if handle_bias:
+                        total_bias = ops.refit_sparse(total_bias, bk, rows=rows, cols=None, sp=1)
+                prev_plan[k] = (perm, sparse)
+                prev_width[k] = n_k
 
             scale = 1.0 / (len(self.models) + 1)
             fused_hat.set_weight_at_layer(layer, (total_weight * scale).reshape(flat_shape))
             if handle_bias:
                 fused_hat.set_bias_at_layer(layer, (total_bias * scale).reshape(n_f))
             prev_is_conv = is_conv
+            nu_prev = nu
 
         if mode == 'acts':
             for model in self.models:

@@ -391,3 +391,101 @@ def weighted_mse(pred, truth, w=None):
         if w.numel() != pred.shape[1]:
             raise ValueError(f'w has {w.numel()} entries for {pred.shape[1]} channels')
     return _WeightedMSE.apply(pred, truth, w)
+
+
+# ---- exact transport with general marginals and the sparse refit --------------------------------------
+
+class SparsePlan:
+    """A transport plan T (n0 x n1) by column: colptr[n1 + 1], rowidx / val[nnz] (val f64), on the device."""
+
+    def __init__(self, n0, n1, colptr, rowidx, val):
+        self.n0, self.n1, self.colptr, self.rowidx, self.val = n0, n1, colptr, rowidx, val
+
+    @property
+    def nnz(self):
+        return self.rowidx.shape[0]
+
+    def colidx(self):
+        counts = (self.colptr[1:] - self.colptr[:-1]).long()
+        return torch.repeat_interleave(torch.arange(self.n1, device=self.colptr.device), counts)
+
+    def dense(self, dtype=torch.float32):
+        T = torch.zeros(self.n0, self.n1, dtype=torch.float64, device=self.val.device)
+        T[self.rowidx.long(), self.colidx()] = self.val
+        return T.to(dtype)
+
+    @staticmethod
+    def from_permutation(row4col, value):
+        """T[row4col[j], j] = value."""
+        n = row4col.shape[0]
+        dev = row4col.device
+        return SparsePlan(n, n, torch.arange(n + 1, device=dev, dtype=torch.int32),
+                          row4col.to(torch.int32).contiguous(),
+                          torch.full((n,), float(value), dtype=torch.float64, device=dev))
+
+    def scaled(self, row_scale=None, col_scale=None):
+        """CSC triplet (colptr, rowidx, f32 values) of diag(row_scale) T diag(col_scale) for nif_refit_sparse."""
+        v = self.val
+        if row_scale is not None:
+            v = v * row_scale.to(v)[self.rowidx.long()]
+        if col_scale is not None:
+            v = v * col_scale.to(v)[self.colidx()]
+        return self.colptr, self.rowidx, v.float().contiguous()
+
+
+def emd_solve(C, a, b, duals=False):
+    """Exact optimal transport plan for cost C (n0 x n1 f32, >= 0) and marginals a, b (``ot.emd(a, b, C)``,
+    otfusion.py:32).  b is rescaled to a's total like POT does.  Returns a SparsePlan (and f64 duals u, v)."""
+    _need_gpu(C, a, b)
+    C = _mat(C.float(), 'C')
+    n0, n1 = C.shape
+    dev = C.device
+    a = a.to(device=dev, dtype=torch.float64).contiguous()
+    b = b.to(device=dev, dtype=torch.float64)
+    b = (b * (a.sum() / b.sum())).contiguous()
+    if a.numel() != n0 or b.numel() != n1:
+        raise ValueError(f'marginals {a.numel()}, {b.numel()} do not match the cost {n0} x {n1}')
+    tol = 1e-13 * float(a.sum())
+    with torch.cuda.device(dev):
+        cap = n0 + n1 + 64
+        colptr = torch.empty(n1 + 1, dtype=torch.int32, device=dev)
+        rowidx = torch.empty(cap, dtype=torch.int32, device=dev)
+        val = torch.empty(cap, dtype=torch.float64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        u = torch.empty(n0, dtype=torch.float64, device=dev)
+        v = torch.empty(n1, dtype=torch.float64, device=dev)
+        wsz = lib.nif_emd_workspace_bytes(n0, n1)
+        if wsz == 0:
+            raise _lib.NifError(f'nif_emd_solve_f32: sizes {n0} x {n1} beyond NIF_EMD_MAX_N')
+        ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+        check(lib.nif_emd_solve_f32(_ptr(C), _ld(C), n0, n1, _ptr(a), _ptr(b), tol, _ptr(colptr), _ptr(rowidx),
+                                    _ptr(val), cap, _ptr(status), _ptr(u), _ptr(v), _ptr(ws), wsz, _stream()),
+              'nif_emd_solve_f32')
+        nnz = int(status.item())
+    if nnz < 0:
+        check(nnz, 'nif_emd_solve_f32 (device status)')
+    plan = SparsePlan(n0, n1, colptr, rowidx[:nnz].contiguous(), val[:nnz].contiguous())
+    return (plan, u, v) if duals else plan
+
+
+def refit_sparse(W0, W1, rows=None, cols=None, alpha=1.0, beta=1.0, sp=1):
+    """out = beta * W0 + alpha * R W1 P with sparse R (n_out x n_k, given as the CSC triplet of its transpose:
+    column j lists the model-k rows feeding fused row j) and sparse P acting on the input units (column q lists
+    the model-k input units feeding fused input q; each unit spans ``sp`` consecutive positions).  None = identity."""
+    _need_gpu(W1, W0)
+    W1 = _mat(W1.float(), 'W1')
+    dev = W1.device
+    n_out = (rows[0].shape[0] - 1) if rows is not None else W1.shape[0]
+    n_in = (cols[0].shape[0] - 1) if cols is not None else W1.shape[1] // sp
+    if W0 is not None:
+        W0 = W0.float().contiguous()
+        if tuple(W0.shape) != (n_out, n_in * sp):
+            raise ValueError(f'W0 is {tuple(W0.shape)}, expected {(n_out, n_in * sp)}')
+    r = rows if rows is not None else (None, None, None)
+    c = cols if cols is not None else (None, None, None)
+    with torch.cuda.device(dev):
+        out = torch.empty((n_out, n_in * sp), dtype=torch.float32, device=dev)
+        check(lib.nif_refit_sparse(_ptr(W0), _ptr(W1), _ld(W1), _ptr(r[0]), _ptr(r[1]), _ptr(r[2]), _ptr(c[0]),
+                                   _ptr(c[1]), _ptr(c[2]), float(alpha), float(beta), n_out, n_in, sp, _ptr(out),
+                                   _stream()), 'nif_refit_sparse')
+    return out

@@ -48,8 +48,11 @@ def ground_metric_wts(aligned_weight, fused_weight):
     return torch.cdist(aligned_weight.flatten(1), fused_weight.flatten(1), p=2)
 
 
-def otf_fuse(models, target_model, X=None, mode='acts', normalize=False, handle_bias=True, log=None):
-    """OTFusion.fuse_models with uniform importance and handle_skip=False, otfusion.py:193-361."""
+def otf_fuse(models, target_model, X=None, mode='acts', normalize=False, handle_bias=True, log=None, scores=None,
+             target_scores=None):
+    """OTFusion.fuse_models with handle_skip=False, otfusion.py:193-361.  scores[k][l] / target_scores[l]:
+    neuron importances already rescaled as otfusion.py:110-112 asks (None = the uniform marginals of
+    :242,258); they are normalised to sum 1 here as :239-240,255-256 do."""
     for m in models:
         m.eval()
     target_model.eval()
@@ -69,12 +72,20 @@ def otf_fuse(models, target_model, X=None, mode='acts', normalize=False, handle_
         layer = fused.get_ordered_trainable_named_layers[l].layer
         total_b = layer.bias.data.clone().detach() if handle_bias else None
         width_f = get_layer_width(fused, l)
-        nu = torch.ones(width_f) / width_f
+        if target_scores is not None:
+            nu = target_scores[l].clone().float()
+            nu = nu / nu.sum()
+        else:
+            nu = torch.ones(width_f) / width_f
         for k, m in enumerate(models):
             wk, _ = get_layer_weight(m, l)
             width_k = get_layer_width(m, l)
             bk = m.get_ordered_trainable_named_layers[l].layer.bias if handle_bias else None
-            mu = torch.ones(width_k) / width_k
+            if scores is not None:
+                mu = scores[k][l].clone().float()
+                mu = mu / mu.sum()
+            else:
+                mu = torch.ones(width_k) / width_k
             Tp = T_prev[k] @ torch.diag(1 / nu_prev)
             if is_conv:
                 edges = (wk.permute(2, 0, 1) @ Tp.unsqueeze(0).repeat(wk.shape[2], 1, 1)).permute(1, 2, 0)

@@ -272,3 +272,48 @@ def test_non_uniform_importance_flows_through_hf_kf_gr_like_the_oracle(dev, name
     raw = [[compute_neuron_importance_scores(method, m, l, X, y, 'layer') for l in range(n_layers)] for m in models]
     ref = o_gr.gr_fuse(cpu_models[0], cpu_models[1], X_cpu, raw[0], raw[1])
     assert_state_close(fused, dict(ref.state_dict()), rtol=1e-3)
+
+
+@pytest.mark.parametrize('name,mode,method', [('mlp_small', 'acts', 'conductance'), ('mlp_wide', 'wts', 'deeplift'),
+                                              ('vgg_tiny', 'acts', 'deeplift'), ('vgg_tiny', 'wts', 'conductance')])
+def test_otfusion_with_importance_marginals_matches_oracle(dev, name, mode, method):
+    """Non-uniform marginals (otfusion.py:239-240,255-256 with :110-112 rescaling): exact transport kernel +
+    sparse refit against the oracle's LP plan + dense products, on the very same scores."""
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import OTFusion
+    from oracle import otfusion as o_otf
+    z = load_npz(name)
+    models, X = build_models(name, z, dev)
+    cpu_models, Xc = build_models(name, z, 'cpu')
+    y = (torch.arange(X.shape[0]) % 10).to(dev)
+    cfg = {'activations_dataset': X, 'activation_labels': y, 'neuron_importance_method': method,
+           'normalize_activations': False, 'rescale_min_importance': 0.2}
+    strategy = {'mode': mode, 'acts': dict(cfg), 'wts': dict(cfg)}
+    otf = OTFusion(models[:-1], models[-1])
+    fused = otf.fuse_models(strategy)
+    assert any(not torch.is_tensor(p) for _, _, p in otf.plans), 'the transport kernel was exercised'
+    for _, _, p in otf.plans:
+        if not torch.is_tensor(p):
+            assert p.nnz <= p.n0 + p.n1 - 1
+    ref = o_otf.otf_fuse(cpu_models[:-1], cpu_models[-1], Xc, mode=mode, scores=otf.neuron_importance_scores,
+                         target_scores=otf.target_neuron_importance_scores)
+    assert_state_close(fused, dict(ref.state_dict()), rtol=1e-3)
+
+
+def test_otfusion_of_models_with_different_widths_matches_oracle(dev):
+    """Unequal widths: rectangular plans even with uniform importance (the reference supports it through ot.emd)."""
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import OTFusion
+    from neuron_interpolation_model_fusion_amd.models import MLPNet
+    from oracle import otfusion as o_otf
+    torch.manual_seed(21)
+    widths = (24, 40, 32)  # two models and the target
+    cpu_models = [MLPNet(20, w, 6, use_bias=True, use_activations=False) for w in widths]
+    Xc = torch.randn(64, 20)
+    models = [m.copy_model().to(dev) for m in cpu_models]
+    for mode in ('acts', 'wts'):
+        strategy = {'mode': mode,
+                    'acts': {'activations_dataset': Xc.to(dev), 'activation_labels': None,
+                             'neuron_importance_method': 'uniform', 'normalize_activations': False},
+                    'wts': {'neuron_importance_method': 'uniform'}}
+        fused = OTFusion(models[:-1], models[-1]).fuse_models(strategy)
+        ref = o_otf.otf_fuse(cpu_models[:-1], cpu_models[-1], Xc, mode=mode)
+        assert_state_close(fused, dict(ref.state_dict()), rtol=1e-3)

@@ -221,3 +221,109 @@ def test_weighted_mse_forward_and_gradient(ops, shape, weighted):
         flat_t = truth.movedim(1, -1).reshape(-1, shape[1]).contiguous().cuda()
         loss_flat = ops.weighted_mse(flat, flat_t, None if w is None else w.cuda())
         np.testing.assert_allclose(loss_flat.item(), ref.item(), rtol=2e-6)
+
+
+def _check_transport_certificate(C, a, b, plan, u, v):
+    """Primal feasibility + dual feasibility + complementary slackness = optimality, no reference solver needed."""
+    T = plan.dense(torch.float64).cpu()
+    C = C.double().cpu()
+    a, b, u, v = a.double().cpu(), b.double().cpu(), u.cpu(), v.cpu()
+    b = b * a.sum() / b.sum()
+    assert (T >= 0).all()
+    assert (T.sum(1) - a).abs().max() <= 1e-11 * a.sum() + 1e-15
+    assert (T.sum(0) - b).abs().max() <= 1e-11 * a.sum() + 1e-15
+    slack = C - u[:, None] - v[None, :]
+    scale = float(C.abs().max()) + 1e-30
+    assert slack.min() >= -1e-9 * scale, 'dual infeasible'
+    assert (slack[T > 0].abs().max() if (T > 0).any() else 0.0) <= 1e-9 * scale, 'support not tight'
+    return float((T * C).sum())
+
+
+@pytest.mark.parametrize('n0,n1', [(1, 1), (1, 7), (9, 1), (5, 5), (17, 30), (64, 64), (130, 90), (384, 384), (700, 1100),
+                                   (2100, 1500)])
+def test_emd_optimality_certificate(ops, n0, n1):
+    g = torch.Generator().manual_seed(n0 * 31 + n1)
+    C = torch.cdist(torch.randn(n0, 12, generator=g), torch.randn(n1, 12, generator=g))
+    a = torch.rand(n0, generator=g) + 0.05
+    b = torch.rand(n1, generator=g) + 0.05
+    a, b = a / a.sum(), b / b.sum()
+    plan, u, v = ops.emd_solve(C.cuda(), a.cuda(), b.cuda(), duals=True)
+    _check_transport_certificate(C, a, b, plan, u, v)
+    assert plan.nnz <= n0 + n1 - 1
+
+
+@pytest.mark.parametrize('n0,n1', [(6, 6), (12, 20), (60, 45), (150, 200)])
+def test_emd_plan_matches_the_lp_oracle(ops, n0, n1):
+    from oracle import otfusion as o
+    g = torch.Generator().manual_seed(n0 + 1000 * n1)
+    C = torch.cdist(torch.randn(n0, 8, generator=g), torch.randn(n1, 8, generator=g))
+    a = torch.rand(n0, generator=g) + 0.1
+    b = torch.rand(n1, generator=g) + 0.1
+    a, b = (a / a.sum()).double(), (b / b.sum()).double()
+    ref = o.emd(a.numpy(), b.numpy(), C.numpy())
+    plan = ops.emd_solve(C.cuda(), a.cuda(), b.cuda())
+    got = plan.dense().cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=3e-7, rtol=1e-4)  # HiGHS' own feasibility tolerance is 1e-7
+
+
+def test_emd_degenerate_and_uniform_cases(ops):
+    """Ties / degenerate vertices: the plan need not be unique, the optimal value is."""
+    g = torch.Generator().manual_seed(5)
+    # uniform square = assignment: same value as the LAP kernel
+    n = 96
+    C = torch.rand(n, n, generator=g)
+    a = torch.full((n,), 1.0 / n)
+    plan, u, v = ops.emd_solve(C.cuda(), a.cuda(), a.cuda(), duals=True)
+    val = _check_transport_certificate(C, a, a, plan, u, v)
+    r, c = linear_sum_assignment(C.double().numpy())
+    np.testing.assert_allclose(val, C.double().numpy()[r, c].sum() / n, rtol=1e-6)  # a = f32(1/n)
+    # uniform rectangular with integer costs: massively degenerate
+    C = torch.randint(0, 4, (8, 12), generator=g).float()
+    a, b = torch.full((8,), 1 / 8), torch.full((12,), 1 / 12)
+    plan, u, v = ops.emd_solve(C.cuda(), a.cuda(), b.cuda(), duals=True)
+    _check_transport_certificate(C, a, b, plan, u, v)
+    # importance scores at the reference's floor (1e-8 before normalisation) on some neurons
+    a = torch.rand(40, generator=g)
+    a[::5] = 1e-8
+    b = torch.rand(40, generator=g)
+    b[3::7] = 1e-8
+    a, b = a / a.sum(), b / b.sum()
+    C = torch.cdist(torch.randn(40, 5, generator=g), torch.randn(40, 5, generator=g))
+    plan, u, v = ops.emd_solve(C.cuda(), a.cuda(), b.cuda(), duals=True)
+    _check_transport_certificate(C, a, b, plan, u, v)
+
+
+def test_refit_sparse_matches_dense_products(ops):
+    g = torch.Generator().manual_seed(9)
+    n_k, n_f, in_k, in_f, sp = 13, 11, 7, 9, 3
+    T = (torch.rand(n_k, n_f, generator=g) < 0.3).double() * torch.rand(n_k, n_f, generator=g).double()
+    Tp = (torch.rand(in_k, in_f, generator=g) < 0.4).double() * torch.rand(in_k, in_f, generator=g).double()
+
+    def csc(M):
+        rows, cols = [], []
+        ptr = [0]
+        vals = []
+        for j in range(M.shape[1]):
+            nz = torch.nonzero(M[:, j]).reshape(-1)
+            rows += nz.tolist()
+            vals += M[nz, j].tolist()
+            ptr.append(len(rows))
+        return ops.SparsePlan(M.shape[0], M.shape[1], torch.tensor(ptr, dtype=torch.int32).cuda(),
+                              torch.tensor(rows, dtype=torch.int32).cuda(), torch.tensor(vals, dtype=torch.float64).cuda())
+    W1 = torch.randn(n_k, in_k * sp, generator=g)
+    W0 = torch.randn(n_f, in_f * sp, generator=g)
+    mu = torch.rand(n_k, generator=g).double() + 0.5
+    nu_prev = torch.rand(in_f, generator=g).double() + 0.5
+    # dense reference: T^T diag(1/mu) W1 [per position] T_prev diag(1/nu_prev)
+    Wk = W1.double().reshape(n_k, in_k, sp)
+    edges = torch.einsum('ips,pq->iqs', Wk, Tp / nu_prev[None, :])
+    ref = 0.25 * W0.double() + 0.5 * torch.einsum('ij,iqs->jqs', T / mu[:, None], edges).reshape(n_f, -1)
+    got = ops.refit_sparse(W0.cuda(), W1.cuda(), rows=csc(T).scaled(row_scale=(1 / mu).cuda()),
+                           cols=csc(Tp).scaled(col_scale=(1 / nu_prev).cuda()), alpha=0.5, beta=0.25, sp=sp)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-6)
+    # identity on either side
+    got = ops.refit_sparse(None, W1.cuda(), rows=None, cols=csc(Tp).scaled(), alpha=1.0, sp=sp)
+    np.testing.assert_allclose(got.cpu().numpy(), torch.einsum('ips,pq->iqs', Wk, Tp).reshape(n_k, -1).numpy(),
+                               rtol=2e-5, atol=2e-6)
+    got = ops.refit_sparse(None, W1.cuda(), rows=csc(T).scaled(), cols=None, alpha=1.0, sp=sp)
+    np.testing.assert_allclose(got.cpu().numpy(), (T.T @ W1.double()).numpy(), rtol=2e-5, atol=2e-6)
