@@ -211,15 +211,18 @@ int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const floa
  * min <T, C> s.t. T 1 = a, T^T 1 = b, T >= 0 for a dense n0 x n1 f32 cost (>= 0) and f64 marginals with equal
  * sums (POT rescales b to a's total; the caller does the same).  Successive shortest augmenting paths, f64
  * duals, one workgroup.  The plan comes back sparse, by column: colptr[n1 + 1], rowidx / val[<= out_cap]
- * (a vertex of the transport polytope has at most n0 + n1 - 1 positive entries).  status[0] (device) = number
- * of entries, or a negative NIF_ERR_*.  tol: flows / supplies below it count as zero (e.g. 1e-13 * sum a).
+ * (a vertex of the transport polytope has at most n0 + n1 - 1 positive entries).  status (device, 4 ints):
+ * [0] = number of entries, or a negative NIF_ERR_*; [1..3] = work counters (augmentations, Dijkstra steps,
+ * rows expanded).  tol: flows / supplies below it count as zero (e.g. 1e-13 * sum a).
  * u / v (optional): optimal duals, u_i + v_j <= C_ij with equality on the support.  Uniform square problems
  * are assignments: use nif_lap_solve_f32 for those. */
 #define NIF_EMD_MAX_N 8192
+#define NIF_EMD_EDGES_GLOBAL 1 /* flags: keep the arc records in the workspace instead of LDS (room for 4 (n0 + n1)
+                                  arcs; retry with it when a degenerate problem returns NIF_ERR_WORKSPACE in status) */
 size_t nif_emd_workspace_bytes(int n0, int n1);
 int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, const double* a, const double* b, double tol,
-                      int32_t* colptr, int32_t* rowidx, double* val, int32_t out_cap, int32_t* status, double* u,
-                      double* v, void* ws, size_t ws_bytes, void* stream);
+                      int flags, int32_t* colptr, int32_t* rowidx, double* val, int32_t out_cap, int32_t* status,
+                      double* u, double* v, void* ws, size_t ws_bytes, void* stream);
 
 /* OTFusion alignment with general (sparse) plans, otfusion.py:261-335:
  * out[j][q*sp + s] = beta * W0[j][q*sp + s]

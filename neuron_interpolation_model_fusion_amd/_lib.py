@@ -19,6 +19,9 @@ NIF_F32, NIF_F64 = 0, 1
 NIF_RELU_A, NIF_RELU_B, NIF_SYMMETRIC, NIF_TRANS_A, NIF_TRANS_B = 1, 2, 4, 8, 16
 NIF_LAP_MAX_N = 8192
 NIF_LAP_SCIPY_ORDER = 1
+NIF_EMD_MAX_N = 8192
+NIF_EMD_EDGES_GLOBAL = 1
+NIF_ERR_WORKSPACE = -2
 
 _c = ctypes
 _vp, _i32, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -46,7 +49,7 @@ SIGNATURES = {
     'nif_refit_pairs': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     'nif_refit_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32, _vp, _vp]),
     'nif_emd_workspace_bytes': (_sz, [_i32, _i32]),
-    'nif_emd_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _c.c_double, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+    'nif_emd_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _c.c_double, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),
     'nif_refit_sparse': (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32,
                                 _vp, _vp]),

@@ -451,17 +451,23 @@ def emd_solve(C, a, b, duals=False):
         colptr = torch.empty(n1 + 1, dtype=torch.int32, device=dev)
         rowidx = torch.empty(cap, dtype=torch.int32, device=dev)
         val = torch.empty(cap, dtype=torch.float64, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = torch.zeros(4, dtype=torch.int32, device=dev)
         u = torch.empty(n0, dtype=torch.float64, device=dev)
         v = torch.empty(n1, dtype=torch.float64, device=dev)
         wsz = lib.nif_emd_workspace_bytes(n0, n1)
         if wsz == 0:
             raise _lib.NifError(f'nif_emd_solve_f32: sizes {n0} x {n1} beyond NIF_EMD_MAX_N')
         ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
-        check(lib.nif_emd_solve_f32(_ptr(C), _ld(C), n0, n1, _ptr(a), _ptr(b), tol, _ptr(colptr), _ptr(rowidx),
-                                    _ptr(val), cap, _ptr(status), _ptr(u), _ptr(v), _ptr(ws), wsz, _stream()),
-              'nif_emd_solve_f32')
-        nnz = int(status.item())
+        for flags in (0, _lib.NIF_EMD_EDGES_GLOBAL):
+            check(lib.nif_emd_solve_f32(_ptr(C), _ld(C), n0, n1, _ptr(a), _ptr(b), tol, flags, _ptr(colptr),
+                                        _ptr(rowidx), _ptr(val), cap, _ptr(status), _ptr(u), _ptr(v), _ptr(ws), wsz,
+                                        _stream()), 'nif_emd_solve_f32')
+            work = status.tolist()
+            if work[0] != _lib.NIF_ERR_WORKSPACE:  # a degenerate problem outgrew the LDS arc pool: retry once
+                break
+        status = work
+        nnz = status[0]
+    emd_solve.last_work = dict(augmentations=status[1], steps=status[2], rows_expanded=status[3])
     if nnz < 0:
         check(nnz, 'nif_emd_solve_f32 (device status)')
     plan = SparsePlan(n0, n1, colptr, rowidx[:nnz].contiguous(), val[:nnz].contiguous())
