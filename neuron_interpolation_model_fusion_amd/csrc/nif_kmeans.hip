@@ -95,6 +95,62 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_kernel(const double
   }
 }
 
+// Same, with the running minimum distance, |y_j|^2 and the label of every neuron held in registers (EPT
+// neurons per lane, N <= 1024 * EPT): a pick then only streams one Gram row.
+template <int EPT>
+__global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const double* __restrict__ G, int64_t ldg,
+                                                                        const double* __restrict__ nn, int N, int k,
+                                                                        int first, int* __restrict__ picks,
+                                                                        int* __restrict__ assign,
+                                                                        double* __restrict__ mind) {
+  __shared__ double sv[16];
+  __shared__ int sj[16];
+  double md[EPT], nj[EPT];
+  int lab[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int j = threadIdx.x + q * 1024;
+    nj[q] = j < N ? nn[j] : 0.0;
+    md[q] = 0.0;
+    lab[q] = 0;
+  }
+  int idx = first;
+  for (int c = 0; c < k; ++c) {
+    if (threadIdx.x == 0) picks[c] = idx;
+    const double* __restrict__ row = G + (int64_t)idx * ldg;
+    const double gii = row[idx];
+    double bv = -INFINITY;
+    int bj = INT_MAX;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int j = threadIdx.x + q * 1024;
+      if (j < N) {
+        double d2 = gii - 2.0 * row[j] + nj[q];
+        if (!(d2 > 0.0)) d2 = 0.0;
+        const double d = sqrt(d2);
+        if (c == 0 || d < md[q]) {
+          md[q] = d;
+          lab[q] = c;
+        }
+        if (md[q] > bv) {  // j ascends within a thread: strict > keeps the lowest index
+          bv = md[q];
+          bj = j;
+        }
+      }
+    }
+    block_argmax(bv, bj, sv, sj);
+    idx = bj;
+  }
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int j = threadIdx.x + q * 1024;
+    if (j < N) {
+      mind[j] = md[q];
+      assign[j] = lab[q];
+    }
+  }
+}
+
 // ---- first assignment from neurons used as centroids (alf.py:221-229) ------------------------------
 // centroid c = neuron c0 + c; assign[j] = argmin_c G[cc][cc] - 2 G[cc][j] + nn[j] (lowest c on ties).
 __global__ void kmeans_assign_to_neurons_kernel(const double* __restrict__ G, int64_t ldg,
@@ -119,38 +175,88 @@ __global__ void kmeans_assign_to_neurons_kernel(const double* __restrict__ G, in
 
 // ---- Lloyd step -----------------------------------------------------------------------------------
 
-// rank[i] = number of i' < i with the same label (stable order inside a cluster); counts[label]++
-__global__ void kmeans_rank_kernel(const int* __restrict__ assign, int N, int* __restrict__ rank,
-                                   int* __restrict__ counts) {
+// counts[label]++ (counts zeroed by the caller)
+__global__ void kmeans_count_kernel(const int* __restrict__ assign, int N, int* __restrict__ counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int lab = assign[i];
-  int r = 0;
-  for (int t = 0; t < i; ++t) r += (assign[t] == lab) ? 1 : 0;
-  rank[i] = r;
-  atomicAdd(&counts[lab], 1);
+  if (i < N) atomicAdd(&counts[assign[i]], 1);
 }
 
 // seg = exclusive scan of counts; compact[c] = index of cluster c among the non-empty ones (or -1);
-// *kprime = number of non-empty clusters.  k is small: one thread.
-__global__ void kmeans_scan_kernel(const int* __restrict__ counts, int k, int* __restrict__ seg,
-                                   int* __restrict__ compact, int* __restrict__ kprime) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int run = 0, live = 0;
-  for (int c = 0; c < k; ++c) {
-    seg[c] = run;
-    run += counts[c];
-    compact[c] = counts[c] > 0 ? live++ : -1;
+// *kprime = number of non-empty clusters.  One workgroup: lane t owns a run of consecutive clusters.
+__global__ __launch_bounds__(1024) void kmeans_scan_kernel(const int* __restrict__ counts, int k,
+                                                           int* __restrict__ seg, int* __restrict__ compact,
+                                                           int* __restrict__ kprime) {
+  __shared__ int wsum[16], wlive[16];
+  const int per = (k + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(lo + per, k);
+  int sum = 0, live = 0;
+  for (int c = lo; c < hi; ++c) {
+    const int n = counts[c];
+    sum += n;
+    live += n > 0 ? 1 : 0;
   }
-  seg[k] = run;
-  *kprime = live;
+  // inclusive scan inside the wave, then over the 16 wave totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int isum = sum, ilive = live;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int a = __shfl_up(isum, o, 64), b = __shfl_up(ilive, o, 64);
+    if (lane >= o) {
+      isum += a;
+      ilive += b;
+    }
+  }
+  if (lane == 63) {
+    wsum[wave] = isum;
+    wlive[wave] = ilive;
+  }
+  __syncthreads();
+  int bsum = 0, blive = 0;
+  for (int w = 0; w < wave; ++w) {
+    bsum += wsum[w];
+    blive += wlive[w];
+  }
+  int run = bsum + isum - sum, lv = blive + ilive - live;
+  for (int c = lo; c < hi; ++c) {
+    const int n = counts[c];
+    seg[c] = run;
+    run += n;
+    compact[c] = n > 0 ? lv++ : -1;
+  }
+  if (threadIdx.x == 1023) {
+    seg[k] = run;
+    *kprime = lv;
+  }
 }
 
-__global__ void kmeans_scatter_kernel(const int* __restrict__ assign, const int* __restrict__ rank,
-                                      const int* __restrict__ seg, int N, int* __restrict__ order) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  order[seg[assign[i]] + rank[i]] = i;
+// order[seg[c] ...] = members of cluster c in ascending index order; one wavefront per cluster sweeps the
+// labels (L2-resident) and compacts its matches with a ballot.
+__global__ __launch_bounds__(256) void kmeans_members_kernel(const int* __restrict__ assign, const int* __restrict__ seg,
+                                                             int N, int k, int* __restrict__ order) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= k) return;
+  const int lane = threadIdx.x & 63;
+  int at = seg[c];
+  const int end = seg[c + 1];
+  for (int i0 = 0; i0 < N && at < end; i0 += 64) {
+    const int i = i0 + lane;
+    const bool mine = i < N && assign[i] == c;
+    const unsigned long long m = __ballot(mine);
+    if (mine) order[at + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    at += __popcll(m);
+  }
+}
+
+// S[cc] = sum of the member weights of cluster c, in member order (one lane per cluster)
+__global__ void kmeans_S_kernel(const float* __restrict__ s, const int* __restrict__ order, const int* __restrict__ seg,
+                                const int* __restrict__ compact, int k, double* __restrict__ S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  const int cc = compact[c];
+  if (cc < 0) return;
+  double tot = 0.0;
+  for (int t = seg[c]; t < seg[c + 1]; ++t) tot += (double)s[order[t]];
+  S[cc] = tot;
 }
 
 // H[cc][j] = sum_{i in c} s_i G[i][j] / S_c for the non-empty cluster c = blockIdx.y (cc = compact[c])
@@ -195,46 +301,66 @@ __global__ void kmeans_cn_kernel(const double* __restrict__ H, const float* __re
 }
 
 // nearest centroid of every neuron (lowest compact label on ties, torch.min's first index),
-// distance, and per-block partial sums of s_j * distance in a fixed order
-__global__ void kmeans_nearest_kernel(const double* __restrict__ H, const double* __restrict__ cn,
-                                      const double* __restrict__ nn, const float* __restrict__ s,
-                                      const int* __restrict__ kprime, int N, int* __restrict__ assign_out,
-                                      double* __restrict__ nearest, double* __restrict__ partial) {
-  __shared__ double red[256];
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// distance, and per-block partial sums of s_j * distance in a fixed order.
+// Block = 64 neurons x 16 wavefronts; wavefront y scans centroids y, y + 16, ... (rows of H, coalesced),
+// then the 16 candidates of a neuron are merged in LDS.
+__global__ __launch_bounds__(1024) void kmeans_nearest_kernel(const double* __restrict__ H,
+                                                              const double* __restrict__ cn,
+                                                              const double* __restrict__ nn,
+                                                              const float* __restrict__ s,
+                                                              const int* __restrict__ kprime, int N,
+                                                              int* __restrict__ assign_out,
+                                                              double* __restrict__ nearest,
+                                                              double* __restrict__ partial) {
+  __shared__ double cand_v[16][64];
+  __shared__ int cand_c[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
   const int kp = *kprime;
-  double contrib = 0.0;
+  double best = INFINITY;
+  int bc = INT_MAX;
   if (j < N) {
     const double nj = nn[j];
-    double best = INFINITY;
-    int bc = 0;
-    for (int cc = 0; cc < kp; ++cc) {
+    for (int cc = ty; cc < kp; cc += 16) {
       const double d2 = cn[cc] - 2.0 * H[(int64_t)cc * N + j] + nj;
       if (d2 < best) {
         best = d2;
         bc = cc;
       }
     }
+  }
+  cand_v[ty][tx] = best;
+  cand_c[ty][tx] = bc;
+  __syncthreads();
+  if (ty != 0) return;
+  for (int y = 1; y < 16; ++y) {
+    const double ov = cand_v[y][tx];
+    const int oc = cand_c[y][tx];
+    if (ov < best || (ov == best && oc < bc)) {
+      best = ov;
+      bc = oc;
+    }
+  }
+  double contrib = 0.0;
+  if (j < N) {
+    if (bc == INT_MAX) bc = 0;
     if (!(best > 0.0)) best = 0.0;
     const double d = sqrt(best);
     assign_out[j] = bc;
     nearest[j] = d;
     contrib = (double)s[j] * d;
   }
-  red[threadIdx.x] = contrib;
-  __syncthreads();
-  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+  contrib = wave_sum_f64(contrib);
+  if (tx == 0) partial[blockIdx.x] = contrib;
 }
 
-__global__ void kmeans_cost_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ cost) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// cost = sum of the per-block partials: lane l adds partial[l], partial[l + 64], ... in order, then a fixed tree
+__global__ __launch_bounds__(64) void kmeans_cost_kernel(const double* __restrict__ partial, int nblocks,
+                                                         double* __restrict__ cost) {
   double t = 0.0;
-  for (int b = 0; b < nblocks; ++b) t += partial[b];
-  *cost = t;
+  for (int b = threadIdx.x; b < nblocks; b += 64) t += partial[b];
+  t = wave_sum_f64(t);
+  if (threadIdx.x == 0) *cost = t;
 }
 
 // ---- KF empty-cluster repair (hf_kf.py:466-471), one workgroup --------------------------------------
@@ -327,6 +453,48 @@ __global__ void kmeans_targets_kernel(const float* __restrict__ A, int64_t lda, 
   }
 }
 
+// Same result through LDS: a block stages R whole rows of A (coalesced, each element read from HBM once), then
+// every lane owns (row, cluster) pairs and walks the cluster's members inside the staged row.
+__global__ void kmeans_targets_lds_kernel(const float* __restrict__ A, int64_t lda, int64_t m,
+                                          const float* __restrict__ w, const int* __restrict__ order,
+                                          const int* __restrict__ seg, const int* __restrict__ compact,
+                                          const double* __restrict__ S, int N, int k, int R,
+                                          float* __restrict__ T, int64_t ldt) {
+  extern __shared__ __attribute__((aligned(16))) float km_tile[];  // [R][N]
+  const int nthreads = blockDim.x;
+  const bool vec = (N % 4 == 0) && (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  for (int64_t r0 = (int64_t)blockIdx.x * R; r0 < m; r0 += (int64_t)gridDim.x * R) {
+    const int rows = (int)((m - r0) < R ? (m - r0) : R);
+    if (vec) {
+      const int n4 = N >> 2;
+      for (int idx = threadIdx.x; idx < rows * n4; idx += nthreads) {
+        const int rr = idx / n4, q = idx - rr * n4;
+        reinterpret_cast<float4*>(km_tile)[rr * n4 + q] =
+            reinterpret_cast<const float4*>(A + (r0 + rr) * lda)[q];
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < rows * N; idx += nthreads) {
+        const int rr = idx / N, q = idx - rr * N;
+        km_tile[rr * N + q] = A[(r0 + rr) * lda + q];
+      }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < rows * k; p += nthreads) {
+      const int rr = p / k, c = p - rr * k;
+      const int cc = compact[c];
+      if (cc < 0) continue;
+      const float* __restrict__ row = km_tile + rr * N;
+      double acc = 0.0;
+      for (int t = seg[c]; t < seg[c + 1]; ++t) {
+        const int i = order[t];
+        acc += (double)w[i] * (double)row[i];
+      }
+      T[(r0 + rr) * ldt + cc] = (float)(acc / S[cc]);
+    }
+    __syncthreads();
+  }
+}
+
 struct KmWs {
   size_t off_rank, off_counts, off_seg, off_compact, off_order, off_H, off_S, off_cn, off_partial, total;
   int nblk;
@@ -343,7 +511,7 @@ static KmWs km_ws(int N, int k) {
   w.off_order = o; o += ka((size_t)N * 4);
   w.off_S = o; o += ka((size_t)k * 8);
   w.off_cn = o; o += ka((size_t)k * 8);
-  w.off_partial = o; o += ka((size_t)w.nblk * 8);
+  w.off_partial = o; o += ka((size_t)((N + 63) / 64) * 8);
   w.off_H = o; o += ka((size_t)k * N * 8);
   w.total = o;
   return w;
@@ -351,15 +519,14 @@ static KmWs km_ws(int N, int k) {
 
 // builds order / seg / compact / kprime for `assign` inside the workspace
 static void km_group(const int* assign, int N, int k, const KmWs& w, unsigned char* b, int* kprime, hipStream_t st) {
-  int* rank = reinterpret_cast<int*>(b + w.off_rank);
   int* counts = reinterpret_cast<int*>(b + w.off_counts);
   int* seg = reinterpret_cast<int*>(b + w.off_seg);
   int* compact = reinterpret_cast<int*>(b + w.off_compact);
   int* order = reinterpret_cast<int*>(b + w.off_order);
   (void)hipMemsetAsync(counts, 0, (size_t)k * 4, st);
-  hipLaunchKernelGGL(kmeans_rank_kernel, dim3(w.nblk), dim3(256), 0, st, assign, N, rank, counts);
-  hipLaunchKernelGGL(kmeans_scan_kernel, dim3(1), dim3(64), 0, st, counts, k, seg, compact, kprime);
-  hipLaunchKernelGGL(kmeans_scatter_kernel, dim3(w.nblk), dim3(256), 0, st, assign, rank, seg, N, order);
+  hipLaunchKernelGGL(kmeans_count_kernel, dim3(w.nblk), dim3(256), 0, st, assign, N, counts);
+  hipLaunchKernelGGL(kmeans_scan_kernel, dim3(1), dim3(1024), 0, st, counts, k, seg, compact, kprime);
+  hipLaunchKernelGGL(kmeans_members_kernel, dim3((k + 3) / 4), dim3(256), 0, st, assign, seg, N, k, order);
 }
 
 }  // namespace nif
@@ -374,10 +541,21 @@ extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const doub
   if (!G || !nn || !picks || !assign || !mind || N <= 0 || k <= 0 || ldg < N || first < 0 || first >= N)
     return NIF_ERR_INVALID_ARG;
   nif::clear_err();
-  int threads = (N + 63) / 64 * 64;
-  if (threads > 1024) threads = 1024;
-  hipLaunchKernelGGL(nif::kmeans_farthest_init_kernel, dim3(1), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream),
-                     G, ldg, nn, N, k, first, picks, assign, mind);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ept = (N + 1023) / 1024;
+#define NIF_FI_GO(E) \
+  hipLaunchKernelGGL(nif::kmeans_farthest_init_reg_kernel<E>, dim3(1), dim3(1024), 0, st, G, ldg, nn, N, k, first, picks, \
+                     assign, mind)
+  if (ept <= 1) NIF_FI_GO(1);
+  else if (ept <= 2) NIF_FI_GO(2);
+  else if (ept <= 4) NIF_FI_GO(4);
+  else if (ept <= 8) NIF_FI_GO(8);
+  else if (ept <= 16) NIF_FI_GO(16);
+  else if (ept <= 32) NIF_FI_GO(32);
+  else
+    hipLaunchKernelGGL(nif::kmeans_farthest_init_kernel, dim3(1), dim3(1024), 0, st, G, ldg, nn, N, k, first, picks,
+                       assign, mind);
+#undef NIF_FI_GO
   return nif::launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 
@@ -413,9 +591,10 @@ extern "C" int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double*
   hipLaunchKernelGGL(kmeans_H_kernel, dim3(w.nblk, k), dim3(256), 0, st, G, ldg, s, order, seg, compact, N, H, S);
   prof_end(NIF_PROF_KMEANS, st);
   hipLaunchKernelGGL(kmeans_cn_kernel, dim3((k + 3) / 4), dim3(256), 0, st, H, s, order, seg, compact, S, N, k, cn);
-  hipLaunchKernelGGL(kmeans_nearest_kernel, dim3(w.nblk), dim3(256), 0, st, H, cn, nn, s, kprime, N, assign_out,
+  const int nb64 = (N + 63) / 64;
+  hipLaunchKernelGGL(kmeans_nearest_kernel, dim3(nb64), dim3(1024), 0, st, H, cn, nn, s, kprime, N, assign_out,
                      nearest, partial);
-  hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1), dim3(64), 0, st, partial, w.nblk, cost);
+  hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1), dim3(64), 0, st, partial, nb64, cost);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 
@@ -465,6 +644,28 @@ extern "C" int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const 
   unsigned char* b = reinterpret_cast<unsigned char*>(ws);
   km_group(assign, N, k, ww, b, kprime, st);
   (void)hipMemset2DAsync(T, (size_t)ldt * sizeof(float), 0, (size_t)k * sizeof(float), (size_t)m, st);
+  int* order = reinterpret_cast<int*>(b + ww.off_order);
+  int* seg = reinterpret_cast<int*>(b + ww.off_seg);
+  int* compact = reinterpret_cast<int*>(b + ww.off_compact);
+  double* S = reinterpret_cast<double*>(b + ww.off_S);
+  const size_t row_bytes = (size_t)N * sizeof(float);
+  if (row_bytes <= 144 * 1024) {
+    // stage whole rows in LDS: up to 16 rows / 64 KB per block for narrow levels, one row for wide ones
+    int R = (int)((64 * 1024) / row_bytes);
+    if (R < 1) R = 1;
+    if (R > 16) R = 16;
+    const size_t lds = (size_t)R * row_bytes;
+    const int threads_l = ((size_t)R * k >= 1024 || lds > 64 * 1024) ? 1024 : 256;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)kmeans_targets_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+    hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w, order, seg, compact, k, S);
+    int64_t blocks = (m + R - 1) / R;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(kmeans_targets_lds_kernel, dim3((unsigned)blocks), dim3(threads_l), lds, st, A, lda, m, w, order,
+                       seg, compact, S, N, k, R, T, ldt);
+    return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+  }
   const int threads = k >= 256 ? 256 : (k + 63) / 64 * 64;
   int64_t gy = m < 16384 ? m : 16384;
   hipLaunchKernelGGL(kmeans_targets_kernel, dim3((k + threads - 1) / threads, (unsigned)gy), dim3(threads), 0, st, A,
