@@ -16,6 +16,9 @@ Inputs are resident in HBM before the timed region.  With N > 1 the fusion sampl
 sharded over the ranks ("strong" scaling: the level is fixed, rows per GPU = m / N); each rank
 builds its partial [G | na | nb] buffer and one RCCL all-reduce (sum, f64) per level combines
 them; the n x n assignment and the refit are replicated.
+Levels are independent (activations are captured once), so the loop is software-pipelined over
+two HIP streams: the Gram (and its all-reduce, on RCCL's stream) of level i + 1 is in flight while
+the single-workgroup assignment and the refit of level i run.  --no-overlap gives the serial loop.
 
 The JSON line also carries
   roofline     : the dominant kernel (nif::xty_kernel, f32 MFMA): algorithmic flops
@@ -57,19 +60,71 @@ def make_level(m_local, n, fan_in, device, seed):
     return dict(act_k=act_k, act_f=act_f, w_k=w_k, w_f=w_f, b_k=b_k, b_f=b_f, prev=prev, perm=perm)
 
 
-def level_step(ops, lv, dist=None):
-    """One fused level on the GPU; returns (col4row, fused weight, fused bias)."""
-    n = lv['act_k'].shape[1]
+def level_front(ops, lv, dist=None):
+    """First half of a level: ground-metric Gram of this rank's rows (+ the all-reduce, left in flight)."""
     G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32')
-    if dist is not None:
-        from neuron_interpolation_model_fusion_amd.parallel import allreduce_gram
-        G, na, nb = allreduce_gram(G, na, nb)  # one packed f64 all-reduce per level
+    if dist is None:
+        return G, na, nb, None, None
+    from neuron_interpolation_model_fusion_amd.parallel import pack_gram
+    buf = pack_gram(G, na, nb)  # one packed f64 all-reduce per level
+    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+    return G, na, nb, buf, work
+
+
+def level_back(ops, lv, front):
+    """Second half: cost, exact assignment, refit; returns (col4row, fused weight, fused bias)."""
+    G, na, nb, buf, work = front
+    if work is not None:
+        from neuron_interpolation_model_fusion_amd.parallel import unpack_gram
+        work.wait()  # the current stream waits for the collective
+        G, na, nb = unpack_gram(buf, G.shape[0], G.shape[1])
     C = ops.cost_dist(G, na, nb)
     col, row, _, _ = ops.lap_solve(C, duals=True)
     # T = P/n, so T^T diag(1/mu) = P^T: target neuron j receives model-k neuron row4col[j]
     w = ops.refit_gather(lv['w_f'], lv['w_k'], rowsrc=row, colsrc=lv['prev'], alpha=0.5, beta=0.5)
     b = ops.refit_gather(lv['b_f'], lv['b_k'], rowsrc=row, alpha=0.5, beta=0.5)
     return col, w, b
+
+
+def level_step(ops, lv, dist=None):
+    """One fused level on the current stream."""
+    return level_back(ops, lv, level_front(ops, lv, dist))
+
+
+class LevelPipeline:
+    """K levels with the front half of level i + 1 issued before the back half of level i, each half on
+    its own stream.  Tensors cross streams, so they are registered with the consumer stream."""
+
+    def __init__(self, ops, lv, dist):
+        self.ops, self.lv, self.dist = ops, lv, dist
+        self.s_front, self.s_back = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run(self, steps):
+        cur = torch.cuda.current_stream()
+        self.s_front.wait_stream(cur)
+        self.s_back.wait_stream(cur)
+        pending, out = None, None
+        for _ in range(steps + 1):
+            nxt = None
+            if _ < steps:
+                with torch.cuda.stream(self.s_front):
+                    front = level_front(self.ops, self.lv, self.dist)
+                    ev = torch.cuda.Event()
+                    ev.record(self.s_front)
+                    for t in front[:4]:
+                        if t is not None:
+                            t.record_stream(self.s_back)
+                nxt = (front, ev)
+            if pending is not None:
+                with torch.cuda.stream(self.s_back):
+                    self.s_back.wait_event(pending[1])
+                    out = level_back(self.ops, self.lv, pending[0])
+            pending = nxt
+        cur.wait_stream(self.s_front)
+        cur.wait_stream(self.s_back)
+        for t in out:
+            t.record_stream(cur)
+        return out
 
 
 def cpu_level(lv_cpu):
@@ -97,6 +152,7 @@ def main():
     ap.add_argument('--rows', type=int, default=M_ROWS)
     ap.add_argument('--width', type=int, default=WIDTH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='serial loop on one stream')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -123,14 +179,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = level_step(ops, lv, dist)
+    pipe = None if args.no_overlap else LevelPipeline(ops, lv, dist)
+
+    def run_levels(count):
+        if count <= 0:
+            return None
+        if pipe is not None:
+            return pipe.run(count)
+        for _ in range(count):
+            res = level_step(ops, lv, dist)
+        return res
+
+    out = run_levels(args.warmup)
     sync()
     ops.profile_collect(ops.PROF_XTY)
     ops.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = level_step(ops, lv, dist)
+    out = run_levels(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     ops.profile_enable(False)
@@ -179,6 +244,7 @@ def main():
                 'parallelism': f'rows sharded over {world} GPU(s), one f64 all-reduce of [G|na|nb] per level'
                                if world > 1 else 'single GPU',
                 'planted_permutation_recovered': recovered,
+                'overlap': 'serial' if args.no_overlap else 'two-stream software pipeline over levels',
             },
             'roofline': {
                 'kernel': 'nif::xty_kernel<float, MmaF32> (v_mfma_f32_32x32x2_f32)',
