@@ -15,6 +15,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/nif.h"
 #include "nif_common.h"
@@ -359,8 +360,15 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
 
+  // columns per lane: a Dijkstra step is a chain of dependent latencies (cost row -> wave reduce -> barrier),
+  // and the barrier / cross-wave part grows with the wave count: 4-8 waves measured best (tools/lap_bench.py)
   int cpt = 1;
+  while (cpt < 4 && (n + cpt - 1) / cpt > 256) cpt *= 2;
   while (cpt < 8 && (n + cpt - 1) / cpt > 1024) cpt *= 2;
+  if (const char* e = getenv("NIF_LAP_CPT")) {  // tuning aid
+    const int c = atoi(e);
+    if ((c == 1 || c == 2 || c == 4 || c == 8) && (n + c - 1) / c <= 1024) cpt = c;
+  }
   int threads = ((n + cpt - 1) / cpt + 63) / 64 * 64;
   if (threads > 1024) return NIF_ERR_UNSUPPORTED;
   const size_t lds =
