@@ -209,12 +209,32 @@ class ALFusion:
         nearest = torch.where(nearest == float('-inf'), torch.tensor(0.0, dtype=nearest.dtype), nearest)
         return assignment, nearest
 
+    def _level_outputs(self, X, level_idx):
+        """Every model's output of level ``level_idx`` on X.  The reference re-runs each model from the input
+        for every level (alf.py:190); the base models do not change during a fusion, so the outputs of the
+        level visited last are kept and the next level is one step further (BaseModel.forward_level)."""
+        key = (X.data_ptr(), tuple(X.shape), tuple(id(m) for m in self.models))
+        cache = getattr(self, '_level_cache', None)
+        acts = None
+        with torch.no_grad():
+            if cache is not None and cache[0] == key:
+                try:
+                    if cache[1] == level_idx:
+                        acts = cache[2]
+                    elif cache[1] == level_idx - 1:
+                        acts = [m.forward_level(a, level_idx) for m, a in zip(self.models, cache[2])]
+                except NotImplementedError:
+                    acts = None
+            if acts is None:
+                acts = [m.forward_until_level(X, level_idx) for m in self.models]
+        self._level_cache = (key, level_idx, acts)
+        return acts
+
     def _k_means_v2(self, level_idx, target_width, fusion_config, level_X):
         X = fusion_config.X
         dev = self.device
         seqlen, height, width = 0, 0, 0
-        with torch.no_grad():
-            acts = [m.forward_until_level(X, level_idx) for m in self.models]
+        acts = self._level_outputs(X, level_idx)
         match_T_to_level_X = fusion_config.align_skip_connections and (acts[0].shape == level_X.shape)
         if is_conv_activation(acts[0]):
             height, width = acts[0].shape[2], acts[0].shape[3]
@@ -332,11 +352,24 @@ class ALFusion:
         raise ValueError(f'Invalid optimizer: {optim_name}')
 
     def _get_level_input(self, level_idx, fused_hat, fusion_config):
+        """Input of level ``level_idx`` of the model being fused (alf.py:476-491).  Levels are fitted in order and
+        the levels below are final, so the previous level's input is carried one level further when it is at hand."""
         if level_idx == 0:
             return fusion_config.X
         fused_hat.eval()
+        key = (fusion_config.X.data_ptr(), tuple(fusion_config.X.shape), id(fused_hat))
+        cache = getattr(self, '_fused_cache', None)
+        out = None
         with torch.no_grad():
-            return fused_hat.forward_until_level(fusion_config.X, level_idx - 1)
+            if cache is not None and cache[0] == key and cache[1] == level_idx - 1:
+                try:
+                    out = fused_hat.forward_level(cache[2], level_idx - 1)
+                except NotImplementedError:
+                    out = None
+            if out is None:
+                out = fused_hat.forward_until_level(fusion_config.X, level_idx - 1)
+        self._fused_cache = (key, level_idx, out)
+        return out
 
     # -- per-level fit (alf.py:493-594) ------------------------------------------------------------------
     @staticmethod
@@ -479,6 +512,7 @@ class ALFusion:
         start_time = time.time()
         self.ni_scores = [{} for _ in range(len(self.models))]
         self.weight_change_per_level = []
+        self._level_cache = self._fused_cache = None
         for k, model in enumerate(self.models):
             for level_idx in range(num_levels):
                 if level_idx in (fusion_config.skip_levels or []):

@@ -61,6 +61,13 @@ class BaseModel(nn.Module, ABC):
         return next(self.parameters()).device
 
     # -- weight write-back (base_model.py:66-79) ----------------------------------
+    def forward_level(self, acts, level_idx):
+        """Output of level ``level_idx`` given the output of level ``level_idx - 1`` (the model input for level
+        0): ``forward_until_level(x, l) == forward_level(forward_until_level(x, l - 1), l)``.  Not part of the
+        reference's API; lets callers walk the levels once instead of re-running the prefix (alf.py:190 does
+        O(levels^2) forwards).  Models that cannot offer it leave this unimplemented."""
+        raise NotImplementedError
+
     def set_weight_at_layer(self, trainable_layer_idx, new_weight):
         layer = self.get_ordered_trainable_named_layers[trainable_layer_idx].layer
         current = layer.weight.data

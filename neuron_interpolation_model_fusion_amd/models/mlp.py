@@ -31,6 +31,9 @@ class MLPNet(BaseModel):
             return x
         return self.level2(x)
 
+    def forward_level(self, acts, level_idx):
+        return self.level1(acts.view(acts.shape[0], -1)) if level_idx == 0 else self.level2(acts)
+
     def copy_model(self):
         twin = MLPNet(self.input_size, self.hidden_size, self.output_size, self.use_bias, self.use_activations,
                       self.train_indices, self.val_indices)

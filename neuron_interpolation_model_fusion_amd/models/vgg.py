@@ -86,6 +86,11 @@ class VGG(BaseModel):
                 return x
         return self.classifier(x)
 
+    def forward_level(self, acts, level_idx):
+        if level_idx < len(self.feature_levels):
+            return self.feature_levels[level_idx](acts)
+        return self.classifier(acts)
+
     def copy_model(self):
         twin = VGG(self.vgg_name, self.num_classes, self.input_shape, batch_norm=self.use_batch_norm,
                    use_bias=self.use_bias, use_activations=self.use_activations)

@@ -104,6 +104,9 @@ class ViT(BaseModel):
                 return x
         return self.fc(x)
 
+    def forward_level(self, acts, level_idx):
+        return self.blocks[level_idx](acts) if level_idx < len(self.blocks) else self.fc(acts)
+
     def copy_model(self):
         twin = ViT(in_c=self.in_c, num_classes=self.num_classes, img_size=self.img_size, patch=self.patch,
                    dropout=self.dropout_p, depth=self.depth, hidden=self.hidden, mlp_hidden=self.mlp_hidden,

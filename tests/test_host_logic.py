@@ -81,3 +81,22 @@ def test_reference_whole_module_checkpoints_load_into_our_classes(tmp_path):
     torch.save(m.copy_model(), tmp_path / 'again.pt')
     again = load_model(tmp_path / 'again.pt')
     assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), m.state_dict().values()))
+
+
+def test_forward_level_walks_the_same_outputs_as_forward_until_level():
+    from neuron_interpolation_model_fusion_amd.models import MLPNet, VGG, ViT
+    torch.manual_seed(0)
+    VGG.cfg.setdefault('VGG_fl_test', [6, 'M', 8, 8, 'M'])
+    cases = [
+        (MLPNet(48, 20, 7, use_bias=True, use_activations=False), torch.randn(5, 3, 4, 4)),
+        (MLPNet(48, 20, 7, use_bias=True, use_activations=True), torch.randn(5, 48)),
+        (VGG('VGG_fl_test', 10, (3, 8, 8), batch_norm=True, use_bias=True, use_activations=False).eval(), torch.randn(4, 3, 8, 8)),
+        (ViT(in_c=3, num_classes=10, img_size=8, patch=4, depth=3, hidden=16, mlp_hidden=32, head=2).eval(), torch.randn(4, 3, 8, 8)),
+    ]
+    for model, X in cases:
+        with torch.no_grad():
+            acts = X
+            for level in range(len(model.get_ordered_trainable_named_levels)):
+                acts = model.forward_level(acts, level)
+                assert torch.equal(acts, model.forward_until_level(X, level)), (type(model).__name__, level)
+            assert torch.equal(acts, model(X))
