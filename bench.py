@@ -17,8 +17,9 @@ sharded over the ranks ("strong" scaling: the level is fixed, rows per GPU = m /
 builds its partial [G | na | nb] buffer and one RCCL all-reduce (sum, f64) per level combines
 them; the n x n assignment and the refit are replicated.
 Levels are independent (activations are captured once), so the loop is software-pipelined over
-two HIP streams: the Gram (and its all-reduce, on RCCL's stream) of level i + 1 is in flight while
-the single-workgroup assignment and the refit of level i run.  --no-overlap gives the serial loop.
+two HIP streams: the Gram and its all-reduce of level i + 1 are in flight while
+the single-workgroup assignment and the refit of level i run.  --no-overlap gives the serial loop; with
+N > 1 the serial loop is the default (see main()).
 
 The JSON line also carries
   roofline     : the dominant kernel (nif::xty_kernel, f32 MFMA): algorithmic flops
@@ -67,16 +68,17 @@ def level_front(ops, lv, dist=None):
         return G, na, nb, None, None
     from neuron_interpolation_model_fusion_amd.parallel import pack_gram
     buf = pack_gram(G, na, nb)  # one packed f64 all-reduce per level
-    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
-    return G, na, nb, buf, work
+    # ordinary stream-ordered collective on the front stream: RCCL runs it on its own stream and the front
+    # stream waits for it, so it overlaps with the back half of the previous level on the other stream
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return G, na, nb, buf, None
 
 
 def level_back(ops, lv, front):
     """Second half: cost, exact assignment, refit; returns (col4row, fused weight, fused bias)."""
-    G, na, nb, buf, work = front
-    if work is not None:
+    G, na, nb, buf, _ = front
+    if buf is not None:
         from neuron_interpolation_model_fusion_amd.parallel import unpack_gram
-        work.wait()  # the current stream waits for the collective
         G, na, nb = unpack_gram(buf, G.shape[0], G.shape[1])
     C = ops.cost_dist(G, na, nb)
     col, row, _, _ = ops.lap_solve(C, duals=True)
@@ -145,6 +147,9 @@ def cpu_level(lv_cpu):
 
 
 def main():
+    if os.environ.get('NIF_BENCH_WATCHDOG'):  # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['NIF_BENCH_WATCHDOG']), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -153,6 +158,9 @@ def main():
     ap.add_argument('--width', type=int, default=WIDTH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='serial loop on one stream')
+    ap.add_argument('--overlap-multi', action='store_true', help='use the two-stream pipeline with N > 1 as well')
+    ap.add_argument('--backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only to rehearse '
+                                                      'the N > 1 code path on a box with fewer GPUs than ranks)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -160,12 +168,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback for the product path)')
+    local_rank %= torch.cuda.device_count()  # ranks share a GPU only in the gloo rehearsal
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.backend)
     from neuron_interpolation_model_fusion_amd import ops
 
     n = args.width
@@ -179,7 +191,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipe = None if args.no_overlap else LevelPipeline(ops, lv, dist)
+    # the two-stream pipeline is used where it could be verified (one GPU); with N > 1 the loop stays serial on the
+    # default stream unless --overlap-multi is given: the overlapped collective could not be exercised on RCCL from
+    # the one-GPU development box, and a stall there would lose the whole scaling run
+    overlap = not args.no_overlap and (world == 1 or args.overlap_multi)
+    pipe = LevelPipeline(ops, lv, dist) if overlap else None
 
     def run_levels(count):
         if count <= 0:
@@ -244,7 +260,7 @@ def main():
                 'parallelism': f'rows sharded over {world} GPU(s), one f64 all-reduce of [G|na|nb] per level'
                                if world > 1 else 'single GPU',
                 'planted_permutation_recovered': recovered,
-                'overlap': 'serial' if args.no_overlap else 'two-stream software pipeline over levels',
+                'overlap': 'two-stream software pipeline over levels' if overlap else 'serial',
             },
             'roofline': {
                 'kernel': 'nif::xty_kernel<float, MmaF32> (v_mfma_f32_32x32x2_f32)',
