@@ -521,6 +521,10 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   // fill the chip (256 CUs x resident workgroups per CU) without leaving a second, nearly empty
   // round of workgroups; keep >= 4 K-tiles per row block
   pl.slots = 256 * (f == 3 ? 2 : (in_f64 || acc == NIF_F64 ? 2 : 4));
+  if (const char* e = getenv("NIF_XTY_SLOTS")) {  // tuning aid: workgroups the split-K aims for
+    const int v = atoi(e);
+    if (v >= 1) pl.slots = v;
+  }
   int64_t target = pl.slots;
   if (pl.ntiles > target) target = pl.ntiles;
   int64_t splits = target / pl.ntiles;
