@@ -80,7 +80,7 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
                           _ptr(G), n1, _ptr(na), _ptr(nb), _ptr(ws), nbytes, _stream()), 'nif_xty')
     if rows_sharded:
         from .parallel import SampleSharding
-        G, na, nb = SampleSharding.reduce(G, na, nb)
+        G, na, nb = SampleSharding.reduce(G, na, nb, symmetric=symmetric)
     return G, na, nb
 
 

@@ -63,3 +63,38 @@ def test_shard_rows_cover_everything():
     G, na, nb = torch.arange(6.).view(2, 3), torch.tensor([1., 2.]), torch.tensor([3., 4., 5.])
     g2, a2, b2 = unpack_gram(pack_gram(G, na, nb), 2, 3)
     assert torch.equal(g2, G.double()) and torch.equal(a2, na.double()) and torch.equal(b2, nb.double())
+
+
+def _worker_sym(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from neuron_interpolation_model_fusion_amd import parallel
+        parallel.TRI_BLOCK = 64  # small blocks so that a small matrix takes the packed path
+        g = torch.Generator().manual_seed(1)
+        m, n = 90, 203  # ragged last block
+        A = torch.randn(m, n, generator=g, dtype=torch.float64)
+        lo, hi = parallel.shard_rows(m)
+        Al = A[lo:hi]
+        Gl, nal = Al.T @ Al, (Al * Al).sum(0)
+        Gl = torch.triu(Gl) + torch.triu(Gl, 1).T  # exactly symmetric partial, as the Gram kernel produces
+        full, na_full, _ = parallel.allreduce_gram(Gl.clone(), nal.clone(), nal.clone())
+        sym, na_sym, nb_sym = parallel.allreduce_gram(Gl.clone(), nal.clone(), nal.clone(), symmetric=True)
+        ok = torch.equal(sym, full) and torch.equal(na_sym, na_full) and torch.equal(nb_sym, na_full)
+        ok = ok and torch.equal(sym, sym.T)
+        # round trip of the packing alone
+        buf = parallel.pack_gram_upper(Gl, nal)
+        assert buf.numel() < n * n + n
+        G2, na2 = parallel.unpack_gram_upper(buf, n)
+        ok = ok and torch.equal(G2, Gl) and torch.equal(na2, nal)
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_symmetric_gram_reduces_only_the_block_upper_triangle():
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_sym, args=(2, _free_port(), out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
