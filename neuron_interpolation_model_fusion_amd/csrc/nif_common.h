@@ -21,6 +21,46 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
   return x;
 }
 
+// ---- wave-wide minimum through DPP row shifts / row broadcasts (no LDS crossbar traffic): the result is
+// returned to every lane.  Lanes without a source keep `old`, the identity of the reduction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int x) {
+  return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+  const int id = -1;  // 0xffffffff
+#define NIF_DPP_STEP(CTRL, RM) x = min(x, (unsigned)dpp_i32<CTRL, RM>(id, (int)x))
+  NIF_DPP_STEP(0x111, 0xf);  // row_shr:1
+  NIF_DPP_STEP(0x112, 0xf);  // row_shr:2
+  NIF_DPP_STEP(0x114, 0xf);  // row_shr:4
+  NIF_DPP_STEP(0x118, 0xf);  // row_shr:8   -> lane 15 of each row of 16 holds the row's minimum
+  NIF_DPP_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  NIF_DPP_STEP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+#undef NIF_DPP_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+__device__ __forceinline__ double wave_min_f64(double x) {
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+#define NIF_DPP_STEP(CTRL, RM)                                                                     \
+  do {                                                                                             \
+    const int lo = dpp_i32<CTRL, RM>(__double2loint(inf), __double2loint(x));                      \
+    const int hi = dpp_i32<CTRL, RM>(__double2hiint(inf), __double2hiint(x));                      \
+    x = fmin(x, __hiloint2double(hi, lo));                                                         \
+  } while (0)
+  NIF_DPP_STEP(0x111, 0xf);
+  NIF_DPP_STEP(0x112, 0xf);
+  NIF_DPP_STEP(0x114, 0xf);
+  NIF_DPP_STEP(0x118, 0xf);
+  NIF_DPP_STEP(0x142, 0xa);
+  NIF_DPP_STEP(0x143, 0xc);
+#undef NIF_DPP_STEP
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+  return __hiloint2double(hi, lo);
+}
+
 // hipGetLastError() is per-thread state shared with every other HIP user in the process (torch's
 // event polling leaves hipErrorNotReady behind), so entry points clear it first and read it after
 // their own launches.

@@ -397,37 +397,31 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
             }
           }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const double ov = shfl_xor_f64(bv, o);
-          const int oj = __shfl_xor(bj, o, 64);
-          const int of = __shfl_xor(bf, o, 64);
-          if (oj != INT_MAX && emd_better(ov, of, oj, bv, bf, bj)) {
-            bv = ov;
-            bf = of;
-            bj = oj;
-          }
-        }
+        // two scalar DPP reductions per wave (see nif_lap.hip): minimal distance, then the smallest key
+        // (no demand left) << 31 | column among the lanes that hold it
+        const bool have = bj != INT_MAX;
+        const unsigned mykey = have ? ((bf ? 0u : 0x80000000u) | (unsigned)bj) : 0xffffffffu;
+        const double wmin = wave_min_f64(have ? bv : INFINITY);
+        const unsigned wkey = wave_min_u32((have && bv == wmin) ? mykey : 0xffffffffu);
         const int pb = (step & 1) * 16;
         ++step;
         if (lane == 0) {
-          redv[pb + wave] = bv;
-          redj[pb + wave] = bj;
-          redf[pb + wave] = bf;
+          redv[pb + wave] = wmin;
+          redj[pb + wave] = (int)wkey;
         }
         __syncthreads();
         bv = redv[pb];
-        bj = redj[pb];
-        bf = redf[pb];
+        unsigned gkey = (unsigned)redj[pb];
         for (int w = 1; w < nw; ++w) {
           const double ov = redv[pb + w];
-          const int oj = redj[pb + w], of = redf[pb + w];
-          if (oj != INT_MAX && emd_better(ov, of, oj, bv, bf, bj)) {
+          const unsigned ok = (unsigned)redj[pb + w];
+          if (ov < bv || (ov == bv && ok < gkey)) {
             bv = ov;
-            bf = of;
-            bj = oj;
+            gkey = ok;
           }
         }
+        bj = gkey == 0xffffffffu ? INT_MAX : (int)(gkey & 0x7fffffffu);
+        bf = (gkey & 0x80000000u) ? 0 : 1;
         if (bj == INT_MAX || !(bv < INFINITY)) break;  // nothing reachable is left
         D = bv;
         if (bf) {

@@ -25,19 +25,13 @@ namespace nif {
 // ---- block-wide arg-extremum over (value, index): larger value wins, lower index on ties -----
 __device__ __forceinline__ void block_argmax(double& v, int& j, double* sv, int* sj) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ov = shfl_xor_f64(v, o);
-    const int oj = __shfl_xor(j, o, 64);
-    if (ov > v || (ov == v && oj < j)) {
-      v = ov;
-      j = oj;
-    }
-  }
+  // two scalar DPP reductions per wave: the maximum, then the lowest index among the lanes that hold it
+  const double wmax = -wave_min_f64(-v);
+  const unsigned widx = wave_min_u32(v == wmax ? (unsigned)j : 0xffffffffu);
   __syncthreads();  // protects sv/sj against readers of the previous call
   if (lane == 0) {
-    sv[wave] = v;
-    sj[wave] = j;
+    sv[wave] = wmax;
+    sj[wave] = (int)widx;
   }
   __syncthreads();
   v = sv[0];
@@ -45,7 +39,7 @@ __device__ __forceinline__ void block_argmax(double& v, int& j, double* sv, int*
   for (int w = 1; w < nw; ++w) {
     const double ov = sv[w];
     const int oj = sj[w];
-    if (ov > v || (ov == v && oj < j)) {
+    if (ov > v || (ov == v && (unsigned)oj < (unsigned)j)) {
       v = ov;
       j = oj;
     }

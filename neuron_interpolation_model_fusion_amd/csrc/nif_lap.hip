@@ -121,7 +121,8 @@ __global__ void lap_zero_init_kernel(int n, double* __restrict__ u, double* __re
 template <int CPT, bool SCIPY>
 __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restrict__ C, int64_t ldc, int n,
                                                            double* __restrict__ u, double* __restrict__ vg,
-                                                           int* __restrict__ col4row_g, int* __restrict__ row4col_g) {
+                                                           int* __restrict__ col4row_g, int* __restrict__ row4col_g,
+                                                           int* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) int lap_sm[];
   int* path = lap_sm;
   int* row4col = lap_sm + n;
@@ -130,7 +131,6 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
   double* redv = reinterpret_cast<double*>(lap_sm + (((SCIPY ? 4 : 3) * n + 3) & ~3));  // [2][16]
   int* redj = reinterpret_cast<int*>(redv + 32);                                         // [2][16]
   int* redf = redj + 32;                                                                 // [2][16]
-  int* redp = redf + 32;                                                                 // [2][16]
 
   const int T = blockDim.x;
   const int tid = threadIdx.x;
@@ -193,45 +193,45 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
           }
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = shfl_xor_f64(bv, o);
-        const int oj = __shfl_xor(bj, o, 64);
-        const int of = __shfl_xor(bf, o, 64);
-        const int op = __shfl_xor(bp, o, 64);
-        if (oj != INT_MAX && (SCIPY ? (bj == INT_MAX || lap_better_scipy(ov, of, op, bv, bf, bp))
-                                    : lap_better(ov, of, oj, bv, bf, bj))) {
-          bv = ov;
-          bf = of;
-          bj = oj;
-          bp = op;
-        }
-      }
+      // block-wide argmin in two scalar reductions: the minimal distance, then -- among the lanes that hold
+      // it -- the smallest tie-break key.  key = (column is matched) << 31 | rank: fast mode ranks by column
+      // index; scipy order ranks free columns by descending position and matched ones by ascending position
+      // (lap_better / lap_better_scipy as a total order).
+      const bool have = bj != INT_MAX;
+      const unsigned mykey = !have ? 0xffffffffu
+                                   : ((bf ? 0u : 0x80000000u) |
+                                      (unsigned)(SCIPY ? (bf ? n - 1 - bp : bp) : bj));
+      const double wmin = wave_min_f64(have ? bv : INFINITY);
+      const unsigned wkey = wave_min_u32((have && bv == wmin) ? mykey : 0xffffffffu);
       const int pb = (step & 1) * 16;
       ++step;
       if (lane == 0) {
-        redv[pb + wave] = bv;
-        redj[pb + wave] = bj;
-        redf[pb + wave] = bf;
-        redp[pb + wave] = bp;
+        redv[pb + wave] = wmin;
+        redj[pb + wave] = (int)wkey;
       }
+      if (have && bv == wmin && mykey == wkey) redf[pb + wave] = bj;  // keys are unique: exactly one lane
       __syncthreads();
-      bv = redv[pb];
-      bj = redj[pb];
-      bf = redf[pb];
-      bp = redp[pb];
+      double gmin = redv[pb];
+      unsigned gkey = (unsigned)redj[pb];
+      int gcol = redf[pb];
       for (int w = 1; w < nw; ++w) {
         const double ov = redv[pb + w];
-        const int oj = redj[pb + w], of = redf[pb + w], op = redp[pb + w];
-        if (oj != INT_MAX && (SCIPY ? (bj == INT_MAX || lap_better_scipy(ov, of, op, bv, bf, bp))
-                                    : lap_better(ov, of, oj, bv, bf, bj))) {
-          bv = ov;
-          bf = of;
-          bj = oj;
-          bp = op;
+        const unsigned ok = (unsigned)redj[pb + w];
+        const int oc = redf[pb + w];
+        if (ov < gmin || (ov == gmin && ok < gkey)) {
+          gmin = ov;
+          gkey = ok;
+          gcol = oc;
         }
       }
-      if (bj == INT_MAX || !(bv < INFINITY)) break;  // no finite candidate (non-finite costs): give up on this row
+      if (gkey == 0xffffffffu || !(gmin < INFINITY)) break;  // no finite candidate (non-finite costs): give up on this row
+      bv = gmin;
+      bf = (gkey & 0x80000000u) ? 0 : 1;
+      bj = gcol;
+      if (SCIPY) {
+        const int r = (int)(gkey & 0x7fffffffu);
+        bp = bf ? n - 1 - r : r;
+      }
       minval = bv;
       const int inext = row4col[bj];
       if (SCIPY) {
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
       col4row_g[j] = col4row[j];
     }
   }
+  if (tid == 0) stats[0] = step;  // Dijkstra steps taken (work counter, read by tools/lap_bench.py)
 }
 
 struct LapWs {
@@ -317,10 +318,10 @@ static LapWs lap_ws(int n) {
 
 template <int CPT, bool SCIPY>
 static void launch_augment(int threads, size_t lds, hipStream_t st, const float* C, int64_t ldc, int n, double* u,
-                           double* v, int* c4r, int* r4c) {
+                           double* v, int* c4r, int* r4c, int* stats) {
   auto kfn = lap_augment_kernel<CPT, SCIPY>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(1), dim3(threads), lds, st, C, ldc, n, u, v, c4r, r4c);
+  hipLaunchKernelGGL(kfn, dim3(1), dim3(threads), lds, st, C, ldc, n, u, v, c4r, r4c, stats);
 }
 
 }  // namespace nif
@@ -376,8 +377,8 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   prof_begin(NIF_PROF_LAP, st);
 #define NIF_LAP_GO(CPT)                                                                       \
   do {                                                                                        \
-    if (scipy_order) launch_augment<CPT, true>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c); \
-    else launch_augment<CPT, false>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c);       \
+    if (scipy_order) launch_augment<CPT, true>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest); \
+    else launch_augment<CPT, false>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest);       \
   } while (0)
   switch (cpt) {
     case 1: NIF_LAP_GO(1); break;

@@ -132,6 +132,7 @@ def lap_solve(C, duals=False, scipy_order=False):
         v = torch.empty(n, dtype=torch.float64, device=C.device) if duals else None
         nbytes = lib.nif_lap_workspace_bytes(n)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=C.device)
+        lap_solve.last_workspace = ws  # tools read the kernel's step counter out of it
         check(lib.nif_lap_solve_f32(_ptr(C), _ld(C), n, _lib.NIF_LAP_SCIPY_ORDER if scipy_order else 0, _ptr(col), _ptr(row), _ptr(u), _ptr(v), _ptr(ws), nbytes,
                                     _stream()), 'nif_lap_solve_f32')
     if duals:

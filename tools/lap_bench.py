@@ -11,6 +11,20 @@ def t(fn, n=3):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
+def steps(n):
+    """Dijkstra steps of the last solve: the kernel leaves the count in the first word of the workspace's jbest area."""
+    a256 = lambda x: (x + 255) & ~255
+    chunks = min((n + 63) // 64, 64)
+    rpc = (n + chunks - 1) // chunks
+    chunks = (n + rpc - 1) // rpc
+    off = a256(chunks * n * 4) + 2 * a256(n * 8)
+    return int(ops.lap_solve.last_workspace[off:off + 4].view(torch.int32).item())
+
+def run(C, scipy_order):
+    ms = t(lambda: ops.lap_solve(C, scipy_order=scipy_order))
+    st = steps(C.shape[0])
+    return f'{ms:.2f} ms / {st} steps = {ms * 1e3 / max(st, 1):.2f} us/step'
+
 g = torch.Generator(device='cuda').manual_seed(0)
 for n in (128, 256, 384, 512, 1024, 2048):
     C = torch.rand(n, n, device='cuda', generator=g)
@@ -18,5 +32,5 @@ for n in (128, 256, 384, 512, 1024, 2048):
     B = torch.randn(1600, n, device='cuda', generator=g).clamp_min(0)
     G, na, nb = ops.xty(A, B)
     Cd = ops.cost_dist(G, na, nb)
-    print(f'n={n}: uniform fast {t(lambda: ops.lap_solve(C)):.2f} ms, scipy-order {t(lambda: ops.lap_solve(C, scipy_order=True)):.2f} ms; '
-          f'unrelated-activations cdist fast {t(lambda: ops.lap_solve(Cd)):.2f} ms, scipy-order {t(lambda: ops.lap_solve(Cd, scipy_order=True)):.2f} ms', flush=True)
+    print(f'n={n}: uniform fast {run(C, False)}, scipy-order {run(C, True)}; '
+          f'unrelated-activations cdist fast {run(Cd, False)}, scipy-order {run(Cd, True)}', flush=True)
