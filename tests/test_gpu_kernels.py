@@ -327,3 +327,105 @@ def test_refit_sparse_matches_dense_products(ops):
                                rtol=2e-5, atol=2e-6)
     got = ops.refit_sparse(None, W1.cuda(), rows=csc(T).scaled(), cols=None, alpha=1.0, sp=sp)
     np.testing.assert_allclose(got.cpu().numpy(), (T.T @ W1.double()).numpy(), rtol=2e-5, atol=2e-6)
+
+
+def _kmeans_problem(N, k, m, seed, empty=()):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(m, N, generator=g)
+    s = torch.rand(N, generator=g) + 0.2
+    assign = torch.randint(0, k, (N,), generator=g)
+    for c in empty:  # leave these labels without members
+        assign[assign == c] = (c + 1) % k
+    return A, s, assign.int()
+
+
+def _ref_lloyd(A, s, assign, k):
+    """Gram-form Lloyd step in f64 on the CPU: compacted centroids, nearest centroid (lowest label on ties)."""
+    A64, s64 = A.double(), s.double()
+    labels = [c for c in range(k) if (assign == c).any()]
+    cents = torch.stack([(A64[:, assign == c] * s64[assign == c]).sum(1) / s64[assign == c].sum() for c in labels], 1)
+    d = torch.cdist(cents.T.contiguous(), A64.T.contiguous())  # k' x N
+    nearest, arg = d.min(0)
+    return arg, nearest, float((nearest * s64).sum()), len(labels), cents
+
+
+@pytest.mark.parametrize('N,k,m,empty', [(50, 7, 40, ()), (300, 64, 64, (3, 10)), (1000, 130, 128, (0,)), (2500, 16, 96, ())])
+def test_kmeans_lloyd_step_matches_f64_reference(ops, N, k, m, empty):
+    A, s, assign = _kmeans_problem(N, k, m, N + k, empty)
+    G, _, _ = ops.xty(A.double().cuda(), None, acc='f64', norms=False)
+    km = ops.KMeans(G, torch.diagonal(G).contiguous(), s.cuda(), k)
+    out, nearest, cost, kp = km.lloyd_step(assign.cuda())
+    arg, near, c, kprime, _ = _ref_lloyd(A, s, assign, k)
+    assert int(kp) == kprime
+    # ties within rounding aside (none in random data), the labels are exact
+    assert (out.cpu().long() == arg).all()
+    # Gram form: a neuron that is its own centroid gets sqrt(cancellation residue) ~ 1e-7 * |x| instead of 0
+    np.testing.assert_allclose(nearest.cpu().numpy(), near.numpy(), rtol=1e-7, atol=2e-6)
+    np.testing.assert_allclose(float(cost), c, rtol=1e-9)
+
+
+@pytest.mark.parametrize('N,k,m', [(50, 7, 33), (771, 100, 20), (4096, 512, 70), (20000, 96, 9), (40001, 12, 5)])
+def test_kmeans_targets_all_staging_variants(ops, N, k, m):
+    """LDS-staged rows (several rows per block, one wide row per block, unaligned width) and the gather fallback."""
+    A, s, assign = _kmeans_problem(N, k, m, N * 3 + k, empty=(1,) if k > 2 else ())
+    km = ops.KMeans(None, torch.zeros(N, dtype=torch.float64).cuda(), s.cuda(), k)
+    T, kp = km.targets(A.cuda(), assign.cuda())
+    _, _, _, kprime, cents = _ref_lloyd(A, s, assign, k)
+    assert int(kp) == kprime and T.shape == (m, k)
+    np.testing.assert_allclose(T[:, :kprime].cpu().numpy(), cents.float().numpy(), rtol=1e-5, atol=1e-6)
+    assert float(T[:, kprime:].abs().max()) == 0.0 if kprime < k else True
+
+
+@pytest.mark.parametrize('N,k', [(64, 5), (300, 20), (3000, 33), (40000, 6)])
+def test_kmeans_farthest_init_matches_sequential_reference(ops, N, k):
+    g = torch.Generator().manual_seed(N)
+    A = torch.randn(24, N, generator=g).double()
+    P = A * 0.9  # "projected" vectors whose Gram feeds the picks; distances go to the raw vectors
+    G = (P.T @ P)
+    nn = (A * A).sum(0)
+    # the kernel's distance: G[p][p] - 2 G[p][j] + nn[j]
+    first = 3
+    picks, mind, lab = [first], None, None
+    for c in range(k):
+        p = picks[c]
+        d = (G[p, p] - 2 * G[p] + nn).clamp_min(0).sqrt()
+        if c == 0:
+            mind, lab = d.clone(), torch.zeros(N, dtype=torch.long)
+        else:
+            upd = d < mind
+            mind[upd], lab[upd] = d[upd], c
+        if c + 1 < k:
+            picks.append(int(torch.argmax(mind)))  # first index of the maximum
+    km = ops.KMeans(G.cuda(), nn.cuda(), torch.ones(N).cuda(), k)
+    got_picks, got_assign = km.farthest_init(first)
+    assert got_picks.cpu().tolist() == picks
+    assert (got_assign.cpu().long() == lab).all()
+    np.testing.assert_allclose(km.mind.cpu().numpy(), mind.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_kmeans_centroid_weights_and_repair(ops):
+    N, k, d = 40, 9, 17
+    g = torch.Generator().manual_seed(2)
+    W = torch.randn(d, N, generator=g).double()
+    s = torch.rand(N, generator=g) + 0.1
+    assign = torch.randint(0, k - 2, (N,), generator=g).int()  # the two top labels are empty
+    km = ops.KMeans(None, torch.zeros(N, dtype=torch.float64).cuda(), s.cuda(), k)
+    rows, kp = km.centroid_weights(W.cuda(), assign.cuda())
+    labels = [c for c in range(k) if (assign == c).any()]
+    assert int(kp) == len(labels)
+    for r, c in enumerate(labels):
+        mask = assign == c
+        ref = (W[:, mask] * s[mask].double()).sum(1) / s[mask].double().sum()
+        np.testing.assert_allclose(rows[r].cpu().numpy(), ref.float().numpy(), rtol=1e-6, atol=1e-7)
+    assert float(rows[len(labels):].abs().max()) == 0.0
+    # repair (hf_kf.py:466-471): every empty label takes the neuron with the largest s * distance, in label order
+    nearest = torch.rand(N, generator=g).double()
+    a_dev, n_dev = assign.clone().cuda(), nearest.clone().cuda()
+    changed = km.repair_kf(a_dev, n_dev, assign.cuda())
+    a_ref, n_ref = assign.clone().long(), nearest.clone()
+    for c in range(k):
+        if not (a_ref == c).any():
+            far = int(torch.argmax(s.double() * n_ref))
+            a_ref[far], n_ref[far] = c, 0.0
+    assert (a_dev.cpu().long() == a_ref).all() and int(changed) == 1
+    np.testing.assert_allclose(n_dev.cpu().numpy(), n_ref.numpy())
