@@ -135,6 +135,7 @@ int nif_cost_hf(const double* G01, int64_t ldg, const double* pp0, const double*
  *   equal distance (first in its `remaining` vector unless a free column ties) -- so
  *   that cost matrices with exact structural ties (dead ReLU neurons give identical
  *   rows / columns) yield scipy's own matching.  Slower: n augmentations instead of a few.
+ * The workspace also receives a work counter (number of Dijkstra steps) for tools/lap_bench.py.
  */
 #define NIF_LAP_MAX_N 8192
 #define NIF_LAP_SCIPY_ORDER 1

@@ -157,35 +157,59 @@ class LSFusion:
             km = ops.KMeans(GP, na, s, output_size)
             best_assignment, best_total_cost = identity, np.inf
             start = time.time()
-            t_init = t_conv = 0.0
-            it_init = it_conv = 0
-            for _ in range(num_k_means_tries):
-                t0 = time.time()
+            # The tries are independent, so they advance in lock step: every round launches one Lloyd step and one
+            # repair per live try and reads all their costs / change flags back with ONE synchronisation, where the
+            # reference's loop (and a try-by-try port) synchronises twice per step.  Each try keeps the exact
+            # control flow of hf_kf.py:448-475; the first-centroid draws come from np.random in try order.
+            t0 = time.time()
+            tries = []
+            main_stream = torch.cuda.current_stream(dev)
+            for t in range(num_k_means_tries):
                 first = int(np.random.randint(low=0, high=output_size))  # a neuron of model 0 (:424)
-                _, assignment = km.farthest_init(first)
-                it_init += output_size - 1
-                t_init += time.time() - t0
-                t0 = time.time()
-                costs_log = []
-                changed = True
-                while changed:
+                solver = km if t == 0 else ops.KMeans(GP, na, s, output_size)  # own workspace per try
+                # the farthest-point pass is one workgroup walking k picks: the tries run side by side on their
+                # own streams (one CU each) instead of queueing behind each other
+                side = torch.cuda.Stream(dev)
+                side.wait_stream(main_stream)
+                with torch.cuda.stream(side):
+                    _, assignment = solver.farthest_init(first)
+                assignment.record_stream(main_stream)
+                tries.append(dict(km=solver, assignment=assignment, costs=[], live=True, stream=side))
+            for tr in tries:
+                main_stream.wait_stream(tr['stream'])
+            it_init = num_k_means_tries * (output_size - 1)
+            torch.cuda.synchronize(dev)
+            t_init = time.time() - t0
+            t0 = time.time()
+            it_conv = 0
+            while any(tr['live'] for tr in tries):
+                live = [tr for tr in tries if tr['live']]
+                flags = []
+                for tr in live:
                     it_conv += 1
-                    prev = assignment
-                    assignment, nearest, cost, _ = km.lloyd_step(prev)
-                    current_cost = float(cost.item())
-                    if len(costs_log) >= k_means_early_stop_steps_check and current_cost >= \
-                            costs_log[-k_means_early_stop_steps_check] * (1.0 - k_means_early_stop_minimum_improvement):
-                        print("K-means Early Stopping at ", len(costs_log), " iterations since ", current_cost, " >= ",
-                              costs_log[-k_means_early_stop_steps_check], "*",
+                    prev = tr['assignment']
+                    assignment, nearest, cost, _ = tr['km'].lloyd_step(prev)
+                    tr['unrepaired'] = assignment.clone()  # kept if this step turns out to be the early stop
+                    changed = tr['km'].repair_kf(assignment, nearest, prev)
+                    tr['assignment'] = assignment
+                    flags.append(torch.stack([cost, changed.double()]))
+                for tr, (current_cost, changed) in zip(live, torch.stack(flags).tolist()):
+                    log = tr['costs']
+                    if len(log) >= k_means_early_stop_steps_check and current_cost >= \
+                            log[-k_means_early_stop_steps_check] * (1.0 - k_means_early_stop_minimum_improvement):
+                        print("K-means Early Stopping at ", len(log), " iterations since ", current_cost, " >= ",
+                              log[-k_means_early_stop_steps_check], "*",
                               (1.0 - k_means_early_stop_minimum_improvement))
-                        break  # before the repair: the un-repaired assignment is kept (:460-462)
-                    costs_log.append(current_cost)
-                    changed = bool(km.repair_kf(assignment, nearest, prev).item())
-                _, _, total, _ = km.lloyd_step(assignment)
-                total_cost = float(total.item())
+                        tr['assignment'] = tr['unrepaired']  # before the repair (:460-462)
+                        tr['live'] = False
+                        continue
+                    log.append(current_cost)
+                    tr['live'] = bool(changed)
+            totals = torch.stack([tr['km'].lloyd_step(tr['assignment'])[2] for tr in tries]).tolist()
+            for tr, total_cost in zip(tries, totals):
                 if total_cost < best_total_cost:
-                    best_assignment, best_total_cost = assignment, total_cost
-                t_conv += time.time() - t0
+                    best_assignment, best_total_cost = tr['assignment'], total_cost
+            t_conv = time.time() - t0
             print(f'K-means time: {(time.time() - start):.2f}, Centroid Initialization Time: {t_init:.2f}, '
                   f'Centroid Initialization Iterations: {it_init}, Centroid Convergence Time: {t_conv:.2f}, '
                   f'Centroid Convergence Iterations: {it_conv}')
