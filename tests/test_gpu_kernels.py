@@ -291,6 +291,17 @@ def test_emd_degenerate_and_uniform_cases(ops):
     C = torch.cdist(torch.randn(40, 5, generator=g), torch.randn(40, 5, generator=g))
     plan, u, v = ops.emd_solve(C.cuda(), a.cuda(), b.cuda(), duals=True)
     _check_transport_certificate(C, a, b, plan, u, v)
+    # exactly zero mass on some neurons (rescale_min_importance = 0 maps the least important neuron to 0)
+    a = torch.rand(30, generator=g)
+    b = torch.rand(45, generator=g)
+    a[::6] = 0.0
+    b[2::9] = 0.0
+    a, b = a / a.sum(), b / b.sum()
+    C = torch.cdist(torch.randn(30, 4, generator=g), torch.randn(45, 4, generator=g))
+    plan, u, v = ops.emd_solve(C.cuda(), a.cuda(), b.cuda(), duals=True)
+    _check_transport_certificate(C, a, b, plan, u, v)
+    T = plan.dense(torch.float64).cpu()
+    assert float(T[::6].abs().max()) == 0.0 and float(T[:, 2::9].abs().max()) == 0.0
 
 
 def test_refit_sparse_matches_dense_products(ops):
