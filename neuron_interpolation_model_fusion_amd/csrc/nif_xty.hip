@@ -509,7 +509,7 @@ struct XtyPlan {
   size_t slab_bytes, nsa_bytes, nsb_bytes, lds_bytes;
 };
 
-static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, int flags) {
+static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, int flags, int slot_div = 1) {
   XtyPlan pl;
   pl.f = f;
   pl.tm = 64 * f;
@@ -521,6 +521,7 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   // fill the chip (256 CUs x resident workgroups per CU) without leaving a second, nearly empty
   // round of workgroups; keep >= 4 K-tiles per row block
   pl.slots = 256 * (f == 3 ? 2 : (in_f64 || acc == NIF_F64 ? 2 : 4));
+  pl.slots /= slot_div;
   if (const char* e = getenv("NIF_XTY_SLOTS")) {  // tuning aid: workgroups the split-K aims for
     const int v = atoi(e);
     if (v >= 1) pl.slots = v;
@@ -548,27 +549,43 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   return pl;
 }
 
-// Estimated duration in arbitrary units: rounds of resident workgroups x work per workgroup / the
-// tile shape's measured MFMA efficiency (192-wide tiles run ~1.12x the rate of 128-wide ones).
-static double plan_cost(const XtyPlan& pl) {
+// Estimated duration in seconds of the Gram kernel plus the slab reduction that follows it.  Rates are the
+// measured ones on MI355X (tools/xty_bench.py): 192-wide f32 tiles 114 TFLOP/s, 128-wide 102, f64 46, with all
+// resident slots filled; leaving half / a quarter of the slots of a CU empty costs 4.5 % / 12 % of that rate,
+// but halves / quarters the split-K slabs the reduction has to stream (1.7 TB/s measured).
+static double plan_cost(const XtyPlan& pl, int slot_div, bool f64_path, size_t esz) {
   const int64_t nblocks = (int64_t)pl.ntiles * pl.splits;
   const int64_t rounds = (nblocks + pl.slots - 1) / pl.slots;
-  const double per_block = (double)pl.rows_per_split * pl.tm * pl.tm;
-  // a round keeps `slots` workgroups resident; fewer resident workgroups per CU each run faster
-  const double speed = (pl.f == 3 ? 1.12 : 1.0) / (pl.slots / 256);
-  return (double)rounds * per_block / speed;
+  const double rate = f64_path ? 46e12 : (pl.f == 3 ? 114e12 : 102e12);
+  const double slow = slot_div == 1 ? 1.0 : (slot_div == 2 ? 1.045 : 1.12);
+  const double gemm = 2.0 * (double)rounds * pl.slots * (double)pl.rows_per_split * pl.tm * pl.tm / rate * slow;
+  const double reduce = (double)pl.splits * pl.n0p * pl.n1p * (double)esz / 1.7e12;
+  return gemm + reduce;
 }
 
 static XtyPlan make_plan(int64_t m, int n0, int n1, int in_f64, int acc, int flags) {
-  XtyPlan p2 = plan_for(2, m, n0, n1, in_f64, acc, flags);
-  if (acc != NIF_F32) return p2;  // the 192-wide tile exists for the f32 matrix path only
-  XtyPlan p3 = plan_for(3, m, n0, n1, in_f64, acc, flags);
-  if (const char* f = getenv("NIF_XTY_FRAGS")) {  // tuning aid
-    const int v = atoi(f);
-    if (v == 2) return p2;
-    if (v == 3) return p3;
+  const bool f64_path = in_f64 || acc != NIF_F32;
+  const size_t esz = acc == NIF_F64 ? 8 : 4;
+  int forced = 0;
+  if (const char* f = getenv("NIF_XTY_FRAGS")) forced = atoi(f);  // tuning aid
+  XtyPlan best{};
+  double best_cost = 0.0;
+  bool have = false;
+  for (int f = 2; f <= 3; ++f) {
+    if (f == 3 && acc != NIF_F32) continue;  // the 192-wide tile exists for the f32 matrix path only
+    if ((forced == 2 || forced == 3) && f != forced) continue;
+    for (int div = 1; div <= 4; div *= 2) {
+      if (f == 3 && div == 4) continue;
+      const XtyPlan pl = plan_for(f, m, n0, n1, in_f64, acc, flags, div);
+      const double c = plan_cost(pl, div, f64_path, esz);
+      if (!have || c < best_cost) {
+        best = pl;
+        best_cost = c;
+        have = true;
+      }
+    }
   }
-  return plan_cost(p3) < plan_cost(p2) ? p3 : p2;
+  return best;
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
