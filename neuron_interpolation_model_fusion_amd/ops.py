@@ -222,12 +222,22 @@ def ls_solve(X, A, normalize=False):
     rtol = max(m, d) * _EPS32
     if m >= d or sharded:
         G, _, _ = xty(X, None, acc='f64', norms=False, rows_sharded=True)
+        # Deflation: a column of X that is exactly zero (a dead ReLU channel of the previous level, times its
+        # kernel taps) is an eigenvector of G with eigenvalue 0 -- pinv drops it and its row of W is 0.  Taking
+        # those out first leaves the same kept eigenpairs on a smaller matrix (eigh is ~d^3).
+        live = G.diagonal() > 0
+        idx = None
+        if int(live.sum().item()) < d:
+            idx = live.nonzero().squeeze(1)
+            G = G.index_select(0, idx).index_select(1, idx)
         lam, V = torch.linalg.eigh(G)
         keep = lam > (rtol * rtol) * lam[-1]
         inv_lam = torch.where(keep, 1.0 / lam, torch.zeros_like(lam))
-        Z, _, _ = xty(V, R, acc='f64', norms=False)          # V^T R
+        Z, _, _ = xty(V, R if idx is None else R.index_select(0, idx), acc='f64', norms=False)   # V^T R
         Z = Z * inv_lam[:, None]
         W, _, _ = xty(V, Z, acc='f64', trans_a=True, norms=False)   # V Z
+        if idx is not None:
+            W = torch.zeros((d, W.shape[1]), dtype=W.dtype, device=W.device).index_copy_(0, idx, W)
     else:
         K, _, _ = xty(X, None, acc='f64', trans_a=True, norms=False)  # X X^T
         lam, U = torch.linalg.eigh(K)

@@ -127,6 +127,32 @@ def test_cost_dist_and_hf(ops):
     assert torch.allclose(Ch.double(), ref_h, rtol=1e-5)
 
 
+@pytest.mark.parametrize('m,d,dead,dup', [(900, 70, 0, 0), (900, 70, 12, 3), (60, 150, 0, 0), (60, 150, 40, 2), (500, 33, 33 - 4, 0)])
+def test_ls_solve_matches_pinv(ops, m, d, dead, dup):
+    """ops.ls_solve against torch.linalg.pinv(X) @ A in f32 semantics (hf_kf.py:213,233-234): full rank, exactly
+    zero columns (dead channels -- the deflated path), duplicated columns (truncation without a zero column), and
+    the dual form (m < d)."""
+    g = torch.Generator().manual_seed(1000 + m + d + dead)
+    X = torch.randn(m, d, generator=g)
+    A = torch.randn(m, 24, generator=g)
+    zero = torch.randperm(d, generator=g)[:dead]
+    X[:, zero] = 0
+    live = [j for j in range(d) if j not in set(zero.tolist())]
+    for t in range(dup):
+        X[:, live[2 * t + 1]] = X[:, live[2 * t]]
+    out = ops.ls_solve(X.cuda(), A.cuda())
+    W = out['W'].cpu()
+    # reference in f64 with the f32 cutoff (pinv on f32 input uses rtol = max(m, d) * eps_f32)
+    X64 = X.double()
+    ref = torch.linalg.pinv(X64, rtol=max(m, d) * 1.1920928955078125e-07) @ A.double()
+    assert out['rank'] == min(m, d - dead - dup)
+    assert (W[zero] == 0).all()
+    assert torch.allclose(W, ref, rtol=1e-6, atol=1e-8 * ref.abs().max().item())
+    # and against the f32 call the reference actually makes, to its own accuracy
+    ref32 = (torch.linalg.pinv(X) @ A).double()
+    assert torch.allclose(W, ref32, rtol=1e-3, atol=1e-4 * ref32.abs().max().item())
+
+
 def _check_lap(ops, C, scipy_order=False):
     n = C.shape[0]
     col, row, u, v = ops.lap_solve(C.cuda(), duals=True, scipy_order=scipy_order)

@@ -10,7 +10,9 @@ log = []
 def traced(X, A, normalize=False):
     out = orig(X, A, normalize)
     m, d = X.shape
-    log.append((m, d, min(m, d), out['rank']))
+    zero_cols = int((X.abs().amax(0) == 0).sum().item())
+    zero_rows = int((X.abs().amax(1) == 0).sum().item())
+    log.append((m, d, min(m, d), out['rank'], zero_cols, zero_rows))
     return out
 ops.ls_solve = traced
 import neuron_interpolation_model_fusion_amd.fusion_algorithms.hf_kf as hk
@@ -24,5 +26,5 @@ torch.manual_seed(0)
 X = torch.randn(400, 3, 32, 32, device=dev)
 with contextlib.redirect_stdout(io.StringIO()):
     LSFusion(models).fuse(X, None, 'hungarian')
-for m, d, full, rank in log:
-    print(f'm={m} d={d} full rank={full} kept={rank} {"TRUNCATED" if rank < full else ""}')
+for m, d, full, rank, zc, zr in log:
+    print(f'm={m} d={d} full rank={full} kept={rank} zero columns={zc} zero rows={zr} {"TRUNCATED" if rank < full else ""}')
