@@ -247,6 +247,14 @@ int nif_wmse_forward(const float* pred, const float* truth, const float* w, int6
 int nif_wmse_backward(const float* pred, const float* truth, const float* w, const float* grad_out, int64_t outer,
                       int C, int64_t inner, float* grad_pred, void* stream);
 
+/* ---- design matrix of a conv level (hf_kf.py:196-208 `F.unfold(...)`, `:224-225` row order, `:204-208` ones
+ * column for the bias) ------------------------------------------------------------------------------
+ * x: [batch][C][H][W] contiguous f32.  out: (batch * OH * OW) x ldo, row (b, oy, ox), column (c, ky, kx) =
+ * x[b][c][oy*sh - ph + ky][ox*sw - pw + kx] (0 outside the image), column C*kh*kw = 1.0 when add_ones, remaining
+ * columns up to ldo = 0 (every one of the ldo columns is written).  OH = (H + 2 ph - kh) / sh + 1, OW likewise. */
+int nif_im2row_f32(const float* x, int64_t batch, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                   int add_ones, float* out, int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,7 @@ SIGNATURES = {
     'nif_wmse_workspace_bytes': (_sz, []),
     'nif_wmse_forward': (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _sz, _vp]),
     'nif_wmse_backward': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    'nif_im2row_f32': (_i32, [_vp, _i64] + [_i32] * 10 + [_vp, _i64, _vp]),
 }
 
 

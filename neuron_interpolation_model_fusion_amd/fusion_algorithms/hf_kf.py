@@ -56,26 +56,32 @@ class LSFusion:
         rep = fused_hat.get_ordered_trainable_named_layers[layer_idx]
         X = fused_hat.get_inputs_and_preactivations(layer_idx)[0]
         in_filters = None
+        use_bias = rep.layer.bias is not None
         if is_conv_weight(rep.weight):
             conv = rep.layer
             in_filters = conv.in_channels
-            X = F.unfold(X, kernel_size=conv.kernel_size, stride=conv.stride, padding=conv.padding)
-            X = X.permute(0, 2, 1).reshape(-1, in_filters * int(np.prod(conv.kernel_size)))
+            if tuple(conv.dilation) != (1, 1):
+                raise ValueError('dilated convolutions are not supported by the LS refit')
+            Xp = ops.design_matrix(X, conv.kernel_size, conv.stride, conv.padding, ones=use_bias)
         else:
-            X = X.reshape(X.shape[0], -1)
-        use_bias = rep.layer.bias is not None
-        d = X.shape[1] + (1 if use_bias else 0)
-        Xp = ops.padded_rows(X.shape[0], d, X.device)
-        Xp[:, :X.shape[1]] = X
-        if use_bias:
-            Xp[:, -1] = 1.0
+            Xp = ops.design_matrix(X, ones=use_bias)
         return Xp, in_filters, use_bias
 
     def _layer_acts(self, models, layer_idx, rows, is_conv):
-        acts = torch.cat(tuple(m.get_inputs_and_preactivations(layer_idx)[1] for m in models), dim=1)
-        if is_conv:
-            acts = acts.permute(0, 2, 3, 1).reshape(rows, -1)
-        return acts.contiguous()
+        """(rows, sum of widths) f32: every model's pre-activations side by side, conv maps as (B, H, W, C) rows
+        (hf_kf.py:224-225) -- each model is copied once, straight into its column slice."""
+        parts = [m.get_inputs_and_preactivations(layer_idx)[1] for m in models]
+        widths = [p.shape[1] for p in parts]
+        out = torch.empty((rows, sum(widths)), dtype=torch.float32, device=parts[0].device)
+        off = 0
+        for p, w in zip(parts, widths):
+            if is_conv:
+                B, _, H, W = p.shape
+                out.view(B, H, W, -1)[..., off:off + w].copy_(p.permute(0, 2, 3, 1))
+            else:
+                out[:, off:off + w].copy_(p.reshape(rows, w))
+            off += w
+        return out
 
     @staticmethod
     def _split_rows(rows, fused_hat, layer_idx, use_bias, is_conv, in_filters):

@@ -193,6 +193,33 @@ def padded_rows(m, d, device, dtype=torch.float32):
     return torch.zeros((m, ld), dtype=dtype, device=device)[:, :d]
 
 
+def design_matrix(x, kernel_size=None, stride=1, padding=0, ones=True):
+    """(m, d) f32 design matrix of a level for the LS refit (hf_kf.py:196-208, 224-225), row stride padded to a
+    multiple of 4 elements: for a conv level (x [B, C, H, W], kernel_size given) the im2col rows ordered
+    (sample, out_y, out_x) with columns (in_channel, ky, kx); for a linear level (kernel_size None) x flattened
+    per sample.  ones=True appends the bias column.  One launch, no intermediate copies."""
+    _need_gpu(x)
+    x = x.contiguous().float()
+    B = x.shape[0]
+    if kernel_size is None:
+        C, H, W = x[0].numel(), 1, 1
+        kh = kw = sh = sw = 1
+        ph = pw = 0
+    else:
+        if x.dim() != 4:
+            raise ValueError(f'design_matrix expects [B, C, H, W] for a conv level, got {tuple(x.shape)}')
+        pair = lambda v: (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+        (kh, kw), (sh, sw), (ph, pw) = pair(kernel_size), pair(stride), pair(padding)
+        C, H, W = x.shape[1:]
+    OH, OW = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    d = C * kh * kw + (1 if ones else 0)
+    ld = (d + 3) // 4 * 4
+    out = torch.empty((B * OH * OW, ld), dtype=torch.float32, device=x.device)
+    check(lib.nif_im2row_f32(_ptr(x), B, C, H, W, kh, kw, sh, sw, ph, pw, 1 if ones else 0, _ptr(out), ld, _stream()),
+          'nif_im2row_f32')
+    return out[:, :d]
+
+
 def ls_solve(X, A, normalize=False):
     """Minimum-norm least squares W = pinv(X) @ A with torch.linalg.pinv's cutoff for f32 inputs
     (singular values <= max(m, d) * eps_f32 * sigma_max are dropped), from normal equations:

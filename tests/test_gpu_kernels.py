@@ -466,3 +466,27 @@ def test_kmeans_centroid_weights_and_repair(ops):
             a_ref[far], n_ref[far] = c, 0.0
     assert (a_dev.cpu().long() == a_ref).all() and int(changed) == 1
     np.testing.assert_allclose(n_dev.cpu().numpy(), n_ref.numpy())
+
+
+@pytest.mark.parametrize('shape,k,stride,pad,ones', [((3, 5, 8, 8), 3, 1, 1, True), ((2, 4, 9, 7), (3, 2), (2, 1), (0, 1), False),
+                                                      ((5, 3, 32, 32), 3, 1, 1, True), ((2, 70, 6, 6), 3, 1, 1, True),
+                                                      ((4, 6, 5, 5), 5, 1, 2, True), ((7, 33), None, 1, 0, True),
+                                                      ((7, 300), None, 1, 0, False)])
+def test_design_matrix_matches_unfold(ops, shape, k, stride, pad, ones):
+    """ops.design_matrix against F.unfold + the reference's row order and ones column (hf_kf.py:196-208, 224-225):
+    bit-exact (it only moves data)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(*shape, generator=g)
+    if k is None:
+        ref = x.reshape(shape[0], -1)
+    else:
+        u = torch.nn.functional.unfold(x, kernel_size=k, stride=stride, padding=pad)
+        ref = u.permute(0, 2, 1).reshape(-1, u.shape[1])
+    if ones:
+        ref = torch.cat([ref, torch.ones(ref.shape[0], 1)], dim=1)
+    out = ops.design_matrix(x.cuda(), k, stride, pad, ones=ones)
+    assert out.shape == ref.shape
+    assert out.stride(0) % 4 == 0
+    assert torch.equal(out.cpu(), ref)
+    base = out.as_strided((out.shape[0], out.stride(0)), (out.stride(0), 1))  # pad columns are written as zeros
+    assert (base[:, out.shape[1]:] == 0).all()
