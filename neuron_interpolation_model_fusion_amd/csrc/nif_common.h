@@ -41,6 +41,29 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
   return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// minimum over a row of 16 lanes (rows 1-3 compute their own): the value lane 15 ends up with
+__device__ __forceinline__ unsigned row16_min_u32(unsigned x) {
+  const int id = -1;
+#define NIF_DPP_STEP(CTRL, RM) x = min(x, (unsigned)dpp_i32<CTRL, RM>(id, (int)x))
+  NIF_DPP_STEP(0x111, 0xf);
+  NIF_DPP_STEP(0x112, 0xf);
+  NIF_DPP_STEP(0x114, 0xf);
+  NIF_DPP_STEP(0x118, 0xf);
+#undef NIF_DPP_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 15);
+}
+
+// order-preserving map of finite / infinite doubles onto unsigned 64-bit integers (-0.0 sorts below +0.0:
+// callers that care add +0.0 first) and back: lets a floating-point minimum run as integer DPP minima
+__device__ __forceinline__ unsigned long long f64_to_ordered(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ordered_to_f64(unsigned long long o) {
+  const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
+  return __longlong_as_double((long long)b);
+}
+
 __device__ __forceinline__ double wave_min_f64(double x) {
   const double inf = __longlong_as_double(0x7ff0000000000000LL);
 #define NIF_DPP_STEP(CTRL, RM)                                                                     \

@@ -88,25 +88,11 @@ __global__ void lap_greedy_finish_kernel(int n, const int* __restrict__ jbest, c
   row4col[t] = (c == INT_MAX) ? -1 : c;
 }
 
-// candidate ordering of one Dijkstra step: smaller distance, then a free column, then the lower index
-__device__ __forceinline__ bool lap_better(double v, int f, int j, double bv, int bf, int bj) {
-  if (v < bv) return true;
-  if (v > bv) return false;
-  if (f != bf) return f > bf;
-  return j < bj;
-}
-
-// scipy-order variant (rectangular_lsap.cpp, augmenting_path): the sequential scan over its
-// `remaining` vector keeps the FIRST column of minimal distance, except that every later FREE
-// column of equal distance replaces the incumbent -- i.e. among the minima: the free column of
-// highest position if any is free, else the column of lowest position.  p = position of the
-// column in `remaining`.
-__device__ __forceinline__ bool lap_better_scipy(double v, int f, int p, double bv, int bf, int bp) {
-  if (v < bv) return true;
-  if (v > bv) return false;
-  if (f != bf) return f > bf;
-  return f ? (p > bp) : (p < bp);
-}
+// Candidate ordering of one Dijkstra step (the tie-break key of lap_augment_kernel).  Fast mode: smaller
+// distance, then a free column, then the lower index.  Scipy order (rectangular_lsap.cpp, augmenting_path): the
+// sequential scan over its `remaining` vector keeps the FIRST column of minimal distance, except that every
+// later FREE column of equal distance replaces the incumbent -- i.e. among the minima: the free column of
+// highest position if any is free, else the column of lowest position.
 
 __global__ void lap_zero_init_kernel(int n, double* __restrict__ u, double* __restrict__ v, int* __restrict__ col4row,
                                      int* __restrict__ row4col) {
@@ -118,6 +104,11 @@ __global__ void lap_zero_init_kernel(int n, double* __restrict__ u, double* __re
   row4col[t] = -1;
 }
 
+// One mailbox per wave and step parity: {distance hi, distance lo (ordered-integer form), tie-break key,
+// column, row matched to that column}; 8 words apart so a lane fetches the first four as one 16-byte read.
+constexpr int LAP_MBOX_WORDS = 8;
+constexpr int LAP_MBOX_TOTAL = 2 * 16 * LAP_MBOX_WORDS;
+
 template <int CPT, bool SCIPY>
 __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restrict__ C, int64_t ldc, int n,
                                                            double* __restrict__ u, double* __restrict__ vg,
@@ -127,16 +118,14 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
   int* path = lap_sm;
   int* row4col = lap_sm + n;
   int* col4row = lap_sm + 2 * n;
-  int* remaining = lap_sm + 3 * n;  // position -> column (scipy-order mode only)
-  double* redv = reinterpret_cast<double*>(lap_sm + (((SCIPY ? 4 : 3) * n + 3) & ~3));  // [2][16]
-  int* redj = reinterpret_cast<int*>(redv + 32);                                         // [2][16]
-  int* redf = redj + 32;                                                                 // [2][16]
+  unsigned* mbox = reinterpret_cast<unsigned*>(lap_sm + ((3 * n + 3) & ~3));
 
   const int T = blockDim.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int nw = T >> 6;
+  constexpr unsigned NONE = 0xffffffffu;
+  constexpr unsigned long long ORD_INF = 0xfff0000000000000ull;  // f64_to_ordered(+inf)
 
   double v[CPT], spc[CPT];
 #pragma unroll
@@ -149,21 +138,37 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
       col4row[j] = col4row_g[j];
     }
   }
+  for (int q = tid; q < LAP_MBOX_TOTAL; q += T) mbox[q] = NONE;  // absent waves never win
   __syncthreads();
+
+  unsigned invalid = 0;
+  int jcl[CPT];  // column index clamped into the matrix: loads need no guard
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int j = tid + c * T;
+    if (j >= n) invalid |= 1u << c;
+    jcl[c] = j < n ? j : 0;
+  }
 
   int step = 0;
   for (int cur = 0; cur < n; ++cur) {
     if (col4row[cur] != -1) continue;  // same LDS word for every thread: uniform
 
-    unsigned scanned = 0;
-    int pos[CPT];
+    // per search: the columns of a lane keep their distance, scanned bit, matched row and tie-break key in
+    // registers -- nothing of a Dijkstra step but the `path` store touches LDS before the reduction.
+    // key = (column is matched) << 31 | rank: fast mode ranks by column index; scipy order ranks free columns
+    // by descending position in scipy's `remaining` vector and matched ones by ascending position.
+    unsigned scanned = invalid;  // columns past n count as scanned
+    unsigned key[CPT];
+    int r4c[CPT];
     int num_remaining = n;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       spc[c] = INFINITY;
+      r4c[c] = row4col[jcl[c]];
       const int j = tid + c * T;
-      pos[c] = n - 1 - j;  // scipy fills `remaining` in reverse order
-      if (SCIPY && j < n) remaining[n - 1 - j] = j;
+      // scipy fills `remaining` in reverse order: column j starts at position n - 1 - j
+      key[c] = r4c[c] == -1 ? (unsigned)j : (0x80000000u | (unsigned)(SCIPY ? n - 1 - j : j));
     }
     int i = cur;
     double minval = 0.0;
@@ -172,84 +177,102 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
     for (int it = 0; it < n; ++it) {
       const double ui = u[i];
       const float* __restrict__ crow = C + (int64_t)i * ldc;
+      float cj[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) cj[c] = crow[jcl[c]];  // all loads in flight together
+      // lane-level candidate: smallest (distance, key)
       double bv = INFINITY;
-      int bj = INT_MAX, bf = 0, bp = 0;
+      unsigned bk = NONE;
+      int bj = -1, bi = -1;
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
-        const int j = tid + c * T;
-        if (j < n && !((scanned >> c) & 1u)) {
-          const double r = minval + (double)crow[j] - ui - v[c];
-          if (r < spc[c]) {
-            spc[c] = r;
-            path[j] = i;
-          }
-          const int f = row4col[j] == -1 ? 1 : 0;
-          if (SCIPY ? (bj == INT_MAX || lap_better_scipy(spc[c], f, pos[c], bv, bf, bp))
-                    : lap_better(spc[c], f, j, bv, bf, bj)) {
-            bv = spc[c];
-            bf = f;
-            bj = j;
-            bp = pos[c];
-          }
+        const bool active = !((scanned >> c) & 1u);
+        const double r = minval + (double)cj[c] - ui - v[c];
+        if (active && r < spc[c]) {
+          spc[c] = r;
+          path[tid + c * T] = i;
+        }
+        const double cand = active ? spc[c] : INFINITY;
+        const unsigned k = active ? key[c] : NONE;
+        if (cand < bv || (cand == bv && k < bk)) {
+          bv = cand;
+          bk = k;
+          bj = tid + c * T;
+          bi = r4c[c];
         }
       }
-      // block-wide argmin in two scalar reductions: the minimal distance, then -- among the lanes that hold
-      // it -- the smallest tie-break key.  key = (column is matched) << 31 | rank: fast mode ranks by column
-      // index; scipy order ranks free columns by descending position and matched ones by ascending position
-      // (lap_better / lap_better_scipy as a total order).
-      const bool have = bj != INT_MAX;
-      const unsigned mykey = !have ? 0xffffffffu
-                                   : ((bf ? 0u : 0x80000000u) |
-                                      (unsigned)(SCIPY ? (bf ? n - 1 - bp : bp) : bj));
-      const double wmin = wave_min_f64(have ? bv : INFINITY);
-      const unsigned wkey = wave_min_u32((have && bv == wmin) ? mykey : 0xffffffffu);
-      const int pb = (step & 1) * 16;
+      // wave-level argmin as integer DPP minima over the ordered form of the distance: high word, and only if
+      // several lanes share it the low word, and only if several still tie the key.  Keys are unique, so one
+      // lane is left; it posts the wave's candidate.
+      const unsigned long long bo = bk == NONE ? ~0ull : f64_to_ordered(bv + 0.0);  // + 0.0: no negative zero
+      const unsigned hi = (unsigned)(bo >> 32), lo = (unsigned)bo;
+      const unsigned whi = wave_min_u32(hi);
+      bool holder = hi == whi;
+      unsigned long long m = __ballot(holder);
+      if (whi != NONE && (m & (m - 1))) {
+        const unsigned wlo = wave_min_u32(holder ? lo : NONE);
+        holder = holder && lo == wlo;
+        m = __ballot(holder);
+        if (m & (m - 1)) {
+          const unsigned wkey = wave_min_u32(holder ? bk : NONE);
+          holder = holder && bk == wkey;
+          m = __ballot(holder);
+        }
+      }
+      const int poster = whi == NONE ? 0 : __ffsll(m) - 1;
+      unsigned* mine = mbox + ((step & 1) * 16 + wave) * LAP_MBOX_WORDS;
+      const unsigned* all = mbox + ((step & 1) * 16 + (lane & 15)) * LAP_MBOX_WORDS;
       ++step;
-      if (lane == 0) {
-        redv[pb + wave] = wmin;
-        redj[pb + wave] = (int)wkey;
+      if (lane == poster) {
+        *reinterpret_cast<uint4*>(mine) = make_uint4(hi, lo, bk, (unsigned)bj);
+        mine[4] = (unsigned)bi;
       }
-      if (have && bv == wmin && mykey == wkey) redf[pb + wave] = bj;  // keys are unique: exactly one lane
       __syncthreads();
-      double gmin = redv[pb];
-      unsigned gkey = (unsigned)redj[pb];
-      int gcol = redf[pb];
-      for (int w = 1; w < nw; ++w) {
-        const double ov = redv[pb + w];
-        const unsigned ok = (unsigned)redj[pb + w];
-        const int oc = redf[pb + w];
-        if (ov < gmin || (ov == gmin && ok < gkey)) {
-          gmin = ov;
-          gkey = ok;
-          gcol = oc;
+      // block-level: lane l of every row of 16 takes wave l's mailbox, same minima over the row
+      const uint4 e = *reinterpret_cast<const uint4*>(all);
+      const unsigned erow = all[4];
+      const unsigned ghi = row16_min_u32(e.x);
+      if (ghi == NONE) break;  // no candidate left
+      bool gholder = e.x == ghi;
+      unsigned gm = (unsigned)__ballot(gholder) & 0xffffu;
+      if (gm & (gm - 1)) {
+        const unsigned glo = row16_min_u32(gholder ? e.y : NONE);
+        gholder = gholder && e.y == glo;
+        gm = (unsigned)__ballot(gholder) & 0xffffu;
+        if (gm & (gm - 1)) {
+          const unsigned gk = row16_min_u32(gholder ? e.z : NONE);
+          gholder = gholder && e.z == gk;
+          gm = (unsigned)__ballot(gholder) & 0xffffu;
         }
       }
-      if (gkey == 0xffffffffu || !(gmin < INFINITY)) break;  // no finite candidate (non-finite costs): give up on this row
-      bv = gmin;
-      bf = (gkey & 0x80000000u) ? 0 : 1;
-      bj = gcol;
+      const int src = __ffs(gm) - 1;
+      const unsigned glo = (unsigned)__builtin_amdgcn_readlane((int)e.y, src);
+      const unsigned gkey = (unsigned)__builtin_amdgcn_readlane((int)e.z, src);
+      const int gcol = __builtin_amdgcn_readlane((int)e.w, src);
+      const int inext = __builtin_amdgcn_readlane((int)erow, src);
+      const unsigned long long gord = ((unsigned long long)ghi << 32) | glo;
+      if (!(gord < ORD_INF)) break;  // no finite candidate (non-finite costs): give up on this row
+      minval = ordered_to_f64(gord);
       if (SCIPY) {
+        // remaining[index] = remaining[--num_remaining]: the column that sat last takes the freed position
         const int r = (int)(gkey & 0x7fffffffu);
-        bp = bf ? n - 1 - r : r;
-      }
-      minval = bv;
-      const int inext = row4col[bj];
-      if (SCIPY) {
-        // remaining[index] = remaining[--num_remaining]
+        const int bp = (gkey & 0x80000000u) ? r : n - 1 - r;
         --num_remaining;
-        const int last = remaining[num_remaining];
-        if (last != bj) {
-          if (tid == 0) remaining[bp] = last;
 #pragma unroll
-          for (int c = 0; c < CPT; ++c)
-            if (tid + c * T == last) pos[c] = bp;
+        for (int c = 0; c < CPT; ++c) {
+          const bool is_free = r4c[c] == -1;
+          const unsigned was_last = is_free ? (unsigned)(n - 1 - num_remaining) : (0x80000000u | (unsigned)num_remaining);
+          const unsigned moved = is_free ? (unsigned)(n - 1 - bp) : (0x80000000u | (unsigned)bp);
+          if (key[c] == was_last) key[c] = moved;
         }
       }
       if (inext == -1) {
-        sink = bj;
+        sink = gcol;
         break;
       }
-      if (tid == bj % T) scanned |= 1u << (bj / T);
+#pragma unroll
+      for (int c = 0; c < CPT; ++c)
+        if (tid + c * T == gcol) scanned |= 1u << c;
       i = inext;
     }
     if (sink < 0) continue;  // uniform; leaves the row unmatched (reported by the caller's check)
@@ -257,11 +280,10 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
     // dual update (scipy rectangular_lsap: u[i] += minVal - spc[col4row[i]], v[j] -= minVal - spc[j])
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      if ((scanned >> c) & 1u) {
-        const int j = tid + c * T;
+      if (((scanned & ~invalid) >> c) & 1u) {
         const double delta = minval - spc[c];
         v[c] -= delta;
-        u[row4col[j]] += delta;
+        u[r4c[c]] += delta;
       }
     }
     if (tid == 0) u[cur] += minval;
@@ -372,8 +394,7 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   }
   int threads = ((n + cpt - 1) / cpt + 63) / 64 * 64;
   if (threads > 1024) return NIF_ERR_UNSUPPORTED;
-  const size_t lds =
-      (size_t)(((scipy_order ? 4 : 3) * n + 3) & ~3) * sizeof(int) + 32 * sizeof(double) + 96 * sizeof(int);
+  const size_t lds = (size_t)((3 * n + 3) & ~3) * sizeof(int) + LAP_MBOX_TOTAL * sizeof(int);
   prof_begin(NIF_PROF_LAP, st);
 #define NIF_LAP_GO(CPT)                                                                       \
   do {                                                                                        \
