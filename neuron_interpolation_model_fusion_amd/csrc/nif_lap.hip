@@ -383,10 +383,10 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
 
-  // columns per lane: a Dijkstra step is a chain of dependent latencies (cost row -> wave reduce -> barrier),
-  // and the barrier / cross-wave part grows with the wave count: 4-8 waves measured best (tools/lap_bench.py)
+  // columns per lane: a Dijkstra step is a chain of dependent latencies (cost row -> relax -> wave minima ->
+  // mailbox + barrier -> row-of-16 minima); the relax part grows with the columns a lane owns while the
+  // cross-wave part no longer depends on the wave count, so as many waves as fit win (tools/lap_bench.py)
   int cpt = 1;
-  while (cpt < 4 && (n + cpt - 1) / cpt > 256) cpt *= 2;
   while (cpt < 8 && (n + cpt - 1) / cpt > 1024) cpt *= 2;
   if (const char* e = getenv("NIF_LAP_CPT")) {  // tuning aid
     const int c = atoi(e);
