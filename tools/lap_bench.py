@@ -34,3 +34,12 @@ for n in (128, 256, 384, 512, 1024, 2048):
     Cd = ops.cost_dist(G, na, nb)
     print(f'n={n}: uniform fast {run(C, False)}, scipy-order {run(C, True)}; '
           f'unrelated-activations cdist fast {run(Cd, False)}, scipy-order {run(Cd, True)}', flush=True)
+
+# planted instances (C3 shape: GR of two MLPs, hidden 8192, B = 4096; and the C2 width)
+for n, m in ((384, 4096), (8192, 4096)):
+    A = torch.randn(m, n, device='cuda', generator=g).clamp_min(0)
+    perm = torch.randperm(n, device='cuda', generator=g)
+    B = 0.9 * A[:, perm] + 0.3 * torch.randn(m, n, device='cuda', generator=g)
+    G, na, nb = ops.xty(A, B)
+    Cd = ops.cost_dist(G, na, nb)
+    print(f'planted n={n}: fast {run(Cd, False)}, scipy-order {run(Cd, True)}', flush=True)
