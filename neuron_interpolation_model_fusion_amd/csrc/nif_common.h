@@ -64,24 +64,21 @@ __device__ __forceinline__ double ordered_to_f64(unsigned long long o) {
   return __longlong_as_double((long long)b);
 }
 
+// wave-wide f64 minimum (finite or infinite inputs, no NaN) as integer DPP minima over the ordered form: the
+// high word, then -- only if several lanes share it -- the low word among them
 __device__ __forceinline__ double wave_min_f64(double x) {
-  const double inf = __longlong_as_double(0x7ff0000000000000LL);
-#define NIF_DPP_STEP(CTRL, RM)                                                                     \
-  do {                                                                                             \
-    const int lo = dpp_i32<CTRL, RM>(__double2loint(inf), __double2loint(x));                      \
-    const int hi = dpp_i32<CTRL, RM>(__double2hiint(inf), __double2hiint(x));                      \
-    x = fmin(x, __hiloint2double(hi, lo));                                                         \
-  } while (0)
-  NIF_DPP_STEP(0x111, 0xf);
-  NIF_DPP_STEP(0x112, 0xf);
-  NIF_DPP_STEP(0x114, 0xf);
-  NIF_DPP_STEP(0x118, 0xf);
-  NIF_DPP_STEP(0x142, 0xa);
-  NIF_DPP_STEP(0x143, 0xc);
-#undef NIF_DPP_STEP
-  const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
-  return __hiloint2double(hi, lo);
+  const unsigned long long o = f64_to_ordered(x);
+  const unsigned hi = (unsigned)(o >> 32), lo = (unsigned)o;
+  const unsigned whi = wave_min_u32(hi);
+  const bool holder = hi == whi;
+  const unsigned long long m = __ballot(holder);
+  unsigned wlo;
+  if (m & (m - 1)) {
+    wlo = wave_min_u32(holder ? lo : 0xffffffffu);
+  } else {
+    wlo = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll(m) - 1);
+  }
+  return ordered_to_f64(((unsigned long long)whi << 32) | wlo);
 }
 
 // hipGetLastError() is per-thread state shared with every other HIP user in the process (torch's
