@@ -174,7 +174,7 @@ def _check_lap(ops, C, scipy_order=False):
     return col, c
 
 
-@pytest.mark.parametrize('n', [1, 2, 7, 10, 64, 100, 256, 384, 513, 1024, 1500, 2048, 3000])
+@pytest.mark.parametrize('n', [1, 2, 7, 10, 64, 100, 256, 384, 513, 1024, 1500, 2048, 3000, 4100])
 def test_lap_random(ops, n):
     g = torch.Generator().manual_seed(n)
     C = torch.rand(n, n, generator=g) * 10
@@ -200,7 +200,7 @@ def test_lap_planted_and_ties(ops):
     _check_lap(ops, torch.randn(300, 300, generator=g))
 
 
-@pytest.mark.parametrize('n', [1, 2, 5, 33, 64, 200, 384, 1025, 2100])
+@pytest.mark.parametrize('n', [1, 2, 5, 33, 64, 200, 384, 1025, 2100, 4100])
 def test_lap_scipy_order_reproduces_scipy_under_ties(ops, n):
     """Structural ties (duplicated rows / columns, constant blocks, small integers): the scipy-order
     mode must return scipy's own col_ind, not just an optimal one."""
