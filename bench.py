@@ -63,7 +63,7 @@ def make_level(m_local, n, fan_in, device, seed):
 
 def level_front(ops, lv, dist=None):
     """First half of a level: ground-metric Gram of this rank's rows (+ the all-reduce, left in flight)."""
-    G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32')
+    G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32', split_bf16=lv.get('split_bf16', False))
     if dist is None:
         return G, na, nb, None, None
     from neuron_interpolation_model_fusion_amd.parallel import pack_gram
@@ -157,6 +157,9 @@ def main():
     ap.add_argument('--rows', type=int, default=M_ROWS)
     ap.add_argument('--width', type=int, default=WIDTH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gram', choices=['f32', 'split-bf16'], default='f32',
+                    help='matrix path of the Gram kernel: exact f32 MFMA (default, the parity path) or six bf16 MFMAs '
+                         'on the exact three-way bf16 split of every operand (f32-level accuracy, different last bits)')
     ap.add_argument('--no-overlap', action='store_true', help='serial loop on one stream')
     ap.add_argument('--overlap-multi', action='store_true', help='use the two-stream pipeline with N > 1 as well')
     ap.add_argument('--backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only to rehearse '
@@ -185,6 +188,7 @@ def main():
     lo = m_total * rank // world
     hi = m_total * (rank + 1) // world
     lv = make_level(hi - lo, n, FAN_IN if n == WIDTH else n, device, seed=1000 + rank)
+    lv['split_bf16'] = args.gram == 'split-bf16'
 
     def sync():
         if dist is not None:
@@ -226,6 +230,7 @@ def main():
     recovered = bool((col == lv['perm']).all())  # model-k neuron i is target neuron perm[i] plus noise
 
     result = None
+    lv.pop('split_bf16')
     if rank == 0:
         # HBM bytes per launch of the dominant kernel from the last committed PMC passes (separate
         # rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled as the microarch guide prescribes)
@@ -233,11 +238,14 @@ def main():
         try:
             with open(os.path.join(ROOT, 'profiles', 'r1_b_xty_traffic.json')) as fh:
                 rec = json.load(fh)
-            if rec.get('shape') == f'm={hi - lo},n={n},f32':
+            if rec.get('shape') == f'm={hi - lo},n={n},f32' and args.gram == 'f32':
                 traffic = rec['hbm_bytes_per_launch']
         except (OSError, ValueError, KeyError):
             pass
         flops = 2.0 * (hi - lo) * n * n
+        # split-bf16: algorithmic flops against the dense bf16 peak (2.5 PF, MI355X_MICROARCH.md); the kernel
+        # executes six times that many
+        peak = F32_MFMA_PEAK_TFLOPS if args.gram == 'f32' else 2500.0
         avg_ms = kernel_ms / max(launches, 1)
         achieved = flops / (avg_ms * 1e-3) / 1e12 if launches else None
         result = {
@@ -251,7 +259,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'f32' if args.gram == 'f32' else 'bf16x3 split of f32 (6 bf16 MFMA terms, f32 accumulate)',
             'data': 'synthetic',
             'config': {
                 'workload': f'C2 OTFusion activation-mode level at ViT width: m={m_total} rows (5000 samples x 65 '
@@ -263,12 +271,13 @@ def main():
                 'overlap': 'two-stream software pipeline over levels' if overlap else 'serial',
             },
             'roofline': {
-                'kernel': 'nif::xty_kernel<float, MmaF32> (v_mfma_f32_32x32x2_f32)',
+                'kernel': 'nif::xty_kernel<float, MmaF32> (v_mfma_f32_32x32x2_f32)' if args.gram == 'f32'
+                          else 'nif::xty_bf16_kernel (v_mfma_f32_32x32x16_bf16, 6 instructions per f32-accurate product)',
                 'bound': 'mfma',
                 'achieved': achieved,
-                'peak': F32_MFMA_PEAK_TFLOPS,
+                'peak': peak,
                 'unit': 'TFLOP/s',
-                'frac': (achieved / F32_MFMA_PEAK_TFLOPS) if achieved else None,
+                'frac': (achieved / peak) if achieved else None,
                 'traffic': traffic,
                 'traffic_unit': 'bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_b_xty_traffic.json)',
                 'algorithmic_bytes_per_launch': 2.0 * (hi - lo) * n * 4,

@@ -44,6 +44,10 @@ extern "C" {
 #define NIF_SYMMETRIC 4   /* B is A (same pointer, n1 == n0): only the upper tile triangle is computed */
 #define NIF_TRANS_A 8     /* A is stored as its transpose: n0 x m row-major (contraction over the contiguous axis) */
 #define NIF_TRANS_B 16    /* same for B */
+#define NIF_XTY_SPLIT_BF16 32 /* f32 in, f32 accumulate, no transposes: every f32 operand is split exactly into
+                                 three bf16 values and the product runs as six bf16 matrix instructions (f32-level
+                                 accuracy at 2.65x the f32 matrix peak; results differ from the default path in the
+                                 last bits) */
 
 int nif_version(void);
 const char* nif_error_string(int code);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libnif.so')
 
 NIF_F32, NIF_F64 = 0, 1
-NIF_RELU_A, NIF_RELU_B, NIF_SYMMETRIC, NIF_TRANS_A, NIF_TRANS_B = 1, 2, 4, 8, 16
+NIF_RELU_A, NIF_RELU_B, NIF_SYMMETRIC, NIF_TRANS_A, NIF_TRANS_B, NIF_XTY_SPLIT_BF16 = 1, 2, 4, 8, 16, 32
 NIF_LAP_MAX_N = 8192
 NIF_LAP_SCIPY_ORDER = 1
 NIF_EMD_MAX_N = 8192

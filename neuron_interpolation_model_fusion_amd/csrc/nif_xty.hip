@@ -459,6 +459,293 @@ __global__ __launch_bounds__(NT, (xty_waves_per_simd<MmaT, FI>())) void xty_kern
   }
 }
 
+// ---- split-bf16 variant (flag NIF_XTY_SPLIT_BF16) -----------------------------------------------------
+// The f32 matrix instruction peaks at 157 TFLOP/s, the bf16 one at 2.5 PFLOP/s.  An f32 value is the exact sum
+// of three bf16 values (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8 significand bits), and a
+// product needs the six cross terms down to 2^-16 (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the dropped
+// ones are below one f32 rounding), each exact in the f32 accumulator of v_mfma_f32_32x32x16_bf16: six bf16
+// matrix instructions of 16 samples each replace eight f32 ones of 2 samples -- 2.65x the f32 peak for a result
+// that is as close to the exact Gram entry as the f32 fma chain is (tools/mfma_probe, tests).
+//
+// Data path: 16-byte global loads of the row-major f32 tile (a dword-per-lane load moves 16 B/clk/CU through the
+// texture addresser whatever its coalescing; only dwordx4 reaches 64 B/clk) -> split in registers -> three
+// row-major bf16 planes [16 samples][128 columns] in LDS -> ds_read_b64_tr_b16, the transposing read of gfx950,
+// hands every lane the 8 consecutive samples of its column that the 32x32x16 operand layout wants.  Rows of a
+// plane are 256 B; 16-byte chunk ch of row r sits at chunk ch ^ (((r & 3) << 2) | ((r >> 2) & 3)), which keeps the
+// transposed reads off each other's banks (cdna_hip_programming.md T10, image (b)).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ unsigned pack_bf16_rn(float a, float b) {
+  f32x2 v = {a, b};
+  union {
+    bf16x2 h;
+    unsigned u;
+  } r;
+  r.h = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32, round to nearest even
+  return r.u;
+}
+// single-instruction f32 helpers: left to itself the compiler packs neighbouring f32 operations into v_pk_*_f32,
+// which stall the matrix pipe they are meant to run beside (MI355X_MICROARCH.md, "price of one filler")
+__device__ __forceinline__ float sub_f32(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void fmac_f32(float& acc, float a, float b) {
+  asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+__device__ __forceinline__ int bf16_plane_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <int FI, bool RELU_A, bool RELU_B>
+__global__ __launch_bounds__(NT, 2) void xty_bf16_kernel(const XtyArgs p) {
+  static_assert(FI == 2, "the split-bf16 kernel is written for 128-wide tiles");
+  constexpr int TM = 128;
+  constexpr int PLANE = BK * TM * 2;  // bytes of one split plane of one operand tile
+  constexpr int OPB = 3 * PLANE;      // one operand: hi, mid, lo
+  constexpr int BUFB = 2 * OPB;       // one buffer: A, B
+  typedef MmaF32<FI, FI> Acc;         // same 32x32 accumulator layout
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7;
+  const int q8 = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (orig >> 3);
+
+  const int split = wg / p.ntiles;
+  int tidx = wg - split * p.ntiles;
+  int ti, tj;
+  if (p.flags & NIF_SYMMETRIC) {
+    ti = 0;
+    int cnt = p.tiles_j;
+    while (tidx >= cnt) {
+      tidx -= cnt;
+      ++ti;
+      --cnt;
+    }
+    tj = ti + tidx;
+  } else {
+    ti = tidx / p.tiles_j;
+    tj = tidx - ti * p.tiles_j;
+  }
+  const int ci = ti * TM, cj = tj * TM;
+
+  const int64_t k_begin = (int64_t)split * p.rows_per_split;
+  int64_t k_end = k_begin + p.rows_per_split;
+  if (k_end > p.m) k_end = p.m;
+  const int nt = k_begin < k_end ? (int)((k_end - k_begin + BK - 1) / BK) : 0;
+  const int ntf = k_begin < k_end ? (int)((k_end - k_begin) / BK) : 0;  // full tiles; nt - ntf is 0 or 1
+  const int last = ntf - 1;
+
+  const float* A = reinterpret_cast<const float*>(p.A);
+  const float* B = reinterpret_cast<const float*>(p.B);
+
+  typename Acc::frag_t acc[FI][FI];
+  Acc::zero(acc);
+
+  const bool want_a = (p.flags & NIF_SYMMETRIC) ? (ti == tj) : (tj == 0);
+  const bool want_b = !(p.flags & NIF_SYMMETRIC) && (ti == 0);
+
+  // Staging map: thread -> 16-byte piece (row srow + 8 h, columns 4 c4 .. + 3) of both operand tiles, h = 0, 1.
+  // Columns past the matrix edge re-read the last valid piece: the padded rows / columns of the slab then hold
+  // finite garbage that nothing reads, and the loop needs no guards.
+  const int srow = tid >> 5, c4 = tid & 31;
+  const int cola = min(ci + 4 * c4, p.n0 - 4), colb = min(cj + 4 * c4, p.n1 - 4);
+  unsigned goffa[2], goffb[2], woff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    goffa[h] = (unsigned)(((srow + 8 * h) * p.lda + cola) * 4);
+    goffb[h] = (unsigned)(((srow + 8 * h) * p.ldb + colb) * 4);
+    woff[h] = (unsigned)(bf16_plane_off(srow + 8 * h, c4 >> 1) + 8 * (c4 & 1));
+  }
+  const char* rowa = reinterpret_cast<const char*>(A + k_begin * p.lda);  // scalar
+  const char* rowb = reinterpret_cast<const char*>(B + k_begin * p.ldb);
+  const int64_t tile_a = (int64_t)BK * p.lda * 4, tile_b = (int64_t)BK * p.ldb * 4;
+  float sqa[4] = {0.f, 0.f, 0.f, 0.f}, sqb[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // full tile tt (samples k_begin + 16 tt .. + 15) -> registers.  The empty asm keeps the 32-bit offsets opaque
+  // inside the loop: hoisted, their zero-extensions would turn the scalar-base addressing into 64-bit vector adds.
+  auto stage = [&](float4 (&x)[2][2], int tt) {
+    const char* ba = rowa + tt * tile_a;
+    const char* bb = rowb + tt * tile_b;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned oa = goffa[h], ob = goffb[h];
+      asm volatile("" : "+v"(oa), "+v"(ob));
+      x[0][h] = *reinterpret_cast<const float4*>(ba + oa);
+      x[1][h] = *reinterpret_cast<const float4*>(bb + ob);
+    }
+  };
+  // the last, partial tile of the last split: rows guarded
+  auto stage_tail = [&](float4 (&x)[2][2], int tt) {
+    const int64_t k0 = k_begin + (int64_t)tt * BK;
+    const char* ba = rowa + tt * tile_a;
+    const char* bb = rowb + tt * tile_b;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool rok = k0 + srow + 8 * h < k_end;
+      x[0][h] = rok ? *reinterpret_cast<const float4*>(ba + goffa[h]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[1][h] = rok ? *reinterpret_cast<const float4*>(bb + goffb[h]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // one 16-byte piece -> 8 bytes in each of the three planes
+  auto split_put = [&](const float4& xi, bool relu, float (&sq)[4], unsigned char* dst) {
+    float v[4] = {xi.x, xi.y, xi.z, xi.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (relu) v[e] = fmaxf(v[e], 0.f);
+      fmac_f32(sq[e], v[e], v[e]);
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx) {
+      const unsigned p01 = pack_bf16_rn(v[0], v[1]);
+      const unsigned p23 = pack_bf16_rn(v[2], v[3]);
+      *reinterpret_cast<uint2*>(dst + sidx * PLANE) = make_uint2(p01, p23);
+      if (sidx < 2) {  // exact residuals
+        v[0] = sub_f32(v[0], __uint_as_float(p01 << 16));
+        v[1] = sub_f32(v[1], __uint_as_float(p01 & 0xffff0000u));
+        v[2] = sub_f32(v[2], __uint_as_float(p23 << 16));
+        v[3] = sub_f32(v[3], __uint_as_float(p23 & 0xffff0000u));
+      }
+    }
+  };
+  auto commit = [&](const float4 (&x)[2][2], int buf) {
+    unsigned char* L = smem_raw + buf * BUFB;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      split_put(x[0][h], RELU_A, sqa, L + woff[h]);
+      split_put(x[1][h], RELU_B, sqb, L + OPB + woff[h]);
+    }
+  };
+
+  // transposed-read addresses: lane (column l & 31 of a 32-wide fragment, k half l >> 5) takes rows
+  // 8 (l >> 5) + 4 jj + 0..3; inside its 16-lane group, lane 4 q + pp supplies row q, columns 4 pp .. + 3.
+  unsigned ra[2][2], rb[2][2];  // [fragment][row block jj]
+  {
+    const int kh = lane >> 5, g1 = (lane >> 4) & 1, l16 = lane & 15, q = l16 >> 2, pp = l16 & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int row = 8 * kh + 4 * jj + q;
+        const int cha = (wi * 64 + 32 * i + 16 * g1) / 8 + (pp >> 1);
+        const int chb = (wj * 64 + 32 * i + 16 * g1) / 8 + (pp >> 1);
+        ra[i][jj] = (unsigned)(bf16_plane_off(row, cha) + 8 * (pp & 1));
+        rb[i][jj] = (unsigned)(OPB + bf16_plane_off(row, chb) + 8 * (pp & 1));
+      }
+  }
+  auto frag8 = [&](int buf, const unsigned (&addr)[2], int sidx) -> bf16x8 {
+    const unsigned char* base = smem_raw + buf * BUFB + sidx * PLANE;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr[0]));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr[1]));
+    union {
+      s16x8 s;
+      bf16x8 v;
+    } u;
+    u.s = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return u.v;
+  };
+  // the 24 matrix instructions of one tile, term by term (smallest first) so that consecutive ones hit different
+  // accumulators; `mid` (the split of a later tile) is spread between them by the issue-order directives
+  auto mma_tile = [&](int buf, auto&& mid) {
+    const bf16x8 a00 = frag8(buf, ra[0], 0), a01 = frag8(buf, ra[1], 0), b00 = frag8(buf, rb[0], 0), b01 = frag8(buf, rb[1], 0);
+    const bf16x8 a20 = frag8(buf, ra[0], 2), a21 = frag8(buf, ra[1], 2), b20 = frag8(buf, rb[0], 2), b21 = frag8(buf, rb[1], 2);
+    const bf16x8 a10 = frag8(buf, ra[0], 1), a11 = frag8(buf, ra[1], 1), b10 = frag8(buf, rb[0], 1), b11 = frag8(buf, rb[1], 1);
+#define NIF_TERM(A0, A1, B0, B1)                                                            \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[0][0], 0, 0, 0);          \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc[0][1], 0, 0, 0);          \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc[1][0], 0, 0, 0);          \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0)
+    NIF_TERM(a20, a21, b00, b01);
+    mid();
+    NIF_TERM(a00, a01, b20, b21);
+    NIF_TERM(a10, a11, b10, b11);
+    NIF_TERM(a10, a11, b00, b01);
+    NIF_TERM(a00, a01, b10, b11);
+    NIF_TERM(a00, a01, b00, b01);
+#undef NIF_TERM
+    // Issue order inside this block: the split arithmetic of the next tile is spread through the matrix
+    // instructions (a wave issues in order; a 32x32x16 instruction occupies the matrix pipe for 32 cycles but
+    // the issue port for 4, so a few vector instructions fit in its shadow) instead of sitting in one lump
+    // during which the matrix pipe drains.
+    __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);  // the fragment reads first
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // five VALU
+      if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // one LDS write
+    }
+  };
+
+  // Two register sets: while tile t computes, tile t + 1 is committed from one set and tile t + 2 is in flight
+  // into the other (a tile of bf16 matrix work is a quarter of the f32 kernel's: a distance of one is too short).
+  float4 xa[2][2], xb[2][2];
+  if (ntf > 0) {
+    stage(xa, 0);
+    stage(xb, min(1, last));
+    commit(xa, 0);
+  }
+  __syncthreads();
+  // tile t reads buffer t & 1 and commits tile t + 1 (unconditionally: one basic block); loads past the end
+  // re-read the last tile and are never committed.  The last full tile runs after the loop without a commit.
+  for (int t = 0; t < last; t += 2) {
+    stage(xa, min(t + 2, last));
+    mma_tile(0, [&] { commit(xb, 1); });
+    __syncthreads();
+    if (t + 1 >= last) break;
+    stage(xb, min(t + 3, last));
+    mma_tile(1, [&] { commit(xa, 0); });
+    __syncthreads();
+  }
+  if (ntf > 0) {
+    mma_tile(last & 1, [] {});
+    __syncthreads();
+  }
+  if (nt > ntf) {  // block-uniform: the partial tile, not pipelined (at most once per launch and split)
+    stage_tail(xa, ntf);
+    commit(xa, 0);
+    __syncthreads();
+    mma_tile(0, [] {});
+    __syncthreads();
+  }
+
+  float* S = reinterpret_cast<float*>(p.slab) + ((int64_t)split * p.n0p + ci + wi * (TM / 2)) * p.n1p + cj + wj * (TM / 2);
+  Acc::store(S, p.n1p, acc, lane);
+
+  // column-norm partials: the eight row groups of a column piece sit in eight threads
+  float* red = reinterpret_cast<float*>(smem_raw);  // [operand][row group][TM]; the tile images are dead
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[srow * TM + 4 * c4 + e] = sqa[e];
+    red[(8 + srow) * TM + 4 * c4 + e] = sqb[e];
+  }
+  __syncthreads();
+  if (tid < TM) {
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      sa += red[r * TM + tid];
+      sb += red[(8 + r) * TM + tid];
+    }
+    if (want_a) reinterpret_cast<float*>(p.nslab_a)[(int64_t)split * p.n0p + ci + tid] = sa;
+    if (want_b) reinterpret_cast<float*>(p.nslab_b)[(int64_t)split * p.n1p + cj + tid] = sb;
+  }
+}
+
 // ---- slab + norm reduction, one launch --------------------------------------------------------------
 // blockIdx.y < n0: row i of G (threads along j); blockIdx.y == n0: na; == n0 + 1: nb.
 template <typename acc_t>
@@ -471,7 +758,8 @@ __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* _
   if (i < n0) {
     if (j >= n1) return;
     int si = i, sj = j;
-    if (symmetric && (i / tm) > (j / tm)) {
+    if (symmetric && i > j) {  // lower triangle = mirror of the upper one, inside diagonal tiles too (the split-bf16
+                               // kernel's term order is not symmetric in i and j)
       si = j;
       sj = i;
     }
@@ -520,7 +808,8 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   pl.ntiles = (flags & NIF_SYMMETRIC) ? pl.tiles_i * (pl.tiles_i + 1) / 2 : pl.tiles_i * pl.tiles_j;
   // fill the chip (256 CUs x resident workgroups per CU) without leaving a second, nearly empty
   // round of workgroups; keep >= 4 K-tiles per row block
-  pl.slots = 256 * (f == 3 ? 2 : (in_f64 || acc == NIF_F64 ? 2 : 4));
+  const bool split_bf16 = (flags & NIF_XTY_SPLIT_BF16) != 0;
+  pl.slots = 256 * (f == 3 ? 2 : (in_f64 || acc == NIF_F64 || split_bf16 ? 2 : 4));
   pl.slots /= slot_div;
   if (const char* e = getenv("NIF_XTY_SLOTS")) {  // tuning aid: workgroups the split-K aims for
     const int v = atoi(e);
@@ -546,6 +835,7 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   const size_t tiles = (size_t)2 * 2 * BK * (pl.tm + 16) * (in_f64 ? 8 : 4);
   const size_t red = (size_t)BK * pl.tm * esz;  // norm reduction scratch aliases the tile images
   pl.lds_bytes = tiles > red ? tiles : red;
+  if (split_bf16) pl.lds_bytes = (size_t)2 * 2 * 3 * BK * pl.tm * 2;  // [buf][operand][3 planes][16][tm] bf16
   return pl;
 }
 
@@ -553,10 +843,10 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
 // measured ones on MI355X (tools/xty_bench.py): 192-wide f32 tiles 114 TFLOP/s, 128-wide 102, f64 46, with all
 // resident slots filled; leaving half / a quarter of the slots of a CU empty costs 4.5 % / 12 % of that rate,
 // but halves / quarters the split-K slabs the reduction has to stream (1.7 TB/s measured).
-static double plan_cost(const XtyPlan& pl, int slot_div, bool f64_path, size_t esz) {
+static double plan_cost(const XtyPlan& pl, int slot_div, bool f64_path, size_t esz, bool split_bf16) {
   const int64_t nblocks = (int64_t)pl.ntiles * pl.splits;
   const int64_t rounds = (nblocks + pl.slots - 1) / pl.slots;
-  const double rate = f64_path ? 46e12 : (pl.f == 3 ? 114e12 : 102e12);
+  const double rate = f64_path ? 46e12 : (split_bf16 ? (pl.f == 3 ? 260e12 : 220e12) : (pl.f == 3 ? 114e12 : 102e12));
   const double slow = slot_div == 1 ? 1.0 : (slot_div == 2 ? 1.045 : 1.12);
   const double gemm = 2.0 * (double)rounds * pl.slots * (double)pl.rows_per_split * pl.tm * pl.tm / rate * slow;
   const double reduce = (double)pl.splits * pl.n0p * pl.n1p * (double)esz / 1.7e12;
@@ -572,12 +862,12 @@ static XtyPlan make_plan(int64_t m, int n0, int n1, int in_f64, int acc, int fla
   double best_cost = 0.0;
   bool have = false;
   for (int f = 2; f <= 3; ++f) {
-    if (f == 3 && acc != NIF_F32) continue;  // the 192-wide tile exists for the f32 matrix path only
+    if (f == 3 && (acc != NIF_F32 || (flags & NIF_XTY_SPLIT_BF16))) continue;  // 192-wide tiles: f32 matrix path only
     if ((forced == 2 || forced == 3) && f != forced) continue;
     for (int div = 1; div <= 4; div *= 2) {
       if (f == 3 && div == 4) continue;
       const XtyPlan pl = plan_for(f, m, n0, n1, in_f64, acc, flags, div);
-      const double c = plan_cost(pl, div, f64_path, esz);
+      const double c = plan_cost(pl, div, f64_path, esz, (flags & NIF_XTY_SPLIT_BF16) != 0);
       if (!have || c < best_cost) {
         best = pl;
         best_cost = c;
@@ -615,6 +905,23 @@ static void launch_variant(const XtyArgs& a, int nblocks, size_t lds, hipStream_
 #undef NIF_XTY_GO
 }
 
+template <int F>
+static void launch_split_bf16(const XtyArgs& a, int nblocks, size_t lds, hipStream_t st) {
+  const bool ra = a.flags & NIF_RELU_A, rb = a.flags & NIF_RELU_B;
+#define NIF_XTY_GO(RA, RB)                                                                               \
+  do {                                                                                                   \
+    auto kfn = xty_bf16_kernel<F, RA, RB>;                                                               \
+    if (lds > 48 * 1024)                                                                                 \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(NT), lds, st, a);                                        \
+  } while (0)
+  if (ra && rb) NIF_XTY_GO(true, true);
+  else if (ra) NIF_XTY_GO(true, false);
+  else if (rb) NIF_XTY_GO(false, true);
+  else NIF_XTY_GO(false, false);
+#undef NIF_XTY_GO
+}
+
 }  // namespace nif
 
 extern "C" size_t nif_xty_workspace_bytes(int64_t m, int n0, int n1, int acc, int flags) {
@@ -622,8 +929,11 @@ extern "C" size_t nif_xty_workspace_bytes(int64_t m, int n0, int n1, int acc, in
   // the plan (tile size, splits) does not depend on the input type except through the resident
   // workgroups per CU: size for the larger of the two
   size_t need = 0;
-  for (int in_f64 = 0; in_f64 < 2; ++in_f64) {
-    const nif::XtyPlan pl = nif::make_plan(m, n0, n1, in_f64, acc, flags);
+  for (int variant = 0; variant < 4; ++variant) {
+    const int in_f64 = variant & 1;
+    // a split-bf16 request may fall back to the f32 matrix path (operand alignment): size for both plans
+    const int fl = (variant & 2) ? (flags & ~NIF_XTY_SPLIT_BF16) : flags;
+    const nif::XtyPlan pl = nif::make_plan(m, n0, n1, in_f64, acc, fl);
     const size_t b = nif::align256(pl.slab_bytes) + nif::align256(pl.nsa_bytes) + nif::align256(pl.nsb_bytes);
     if (b > need) need = b;
   }
@@ -644,6 +954,13 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
   if ((ta || tb) && (flags & (NIF_RELU_A | NIF_RELU_B))) return NIF_ERR_UNSUPPORTED;
   if ((flags & NIF_SYMMETRIC) && (((flags & NIF_RELU_A) != 0) != ((flags & NIF_RELU_B) != 0)))
     return NIF_ERR_INVALID_ARG;
+  if ((flags & NIF_XTY_SPLIT_BF16) && (in_dtype != NIF_F32 || acc != NIF_F32 || ta || tb)) return NIF_ERR_UNSUPPORTED;
+  if (flags & NIF_XTY_SPLIT_BF16) {
+    // the split kernel moves 16-byte pieces of rows: operands it cannot address that way take the f32 matrix path
+    const bool ok = reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0 && lda % 4 == 0 &&
+                    ldb % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && lda < (1 << 24) && ldb < (1 << 24);
+    if (!ok) flags &= ~NIF_XTY_SPLIT_BF16;
+  }
   const XtyPlan pl = make_plan(m, n0, n1, in_dtype == NIF_F64, acc, flags);
   const size_t need = align256(pl.slab_bytes) + align256(pl.nsa_bytes) + align256(pl.nsb_bytes);
   if (!ws || ws_bytes < need) return NIF_ERR_WORKSPACE;
@@ -667,7 +984,9 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
   size_t lds = pl.lds_bytes;
   if (const char* pad = getenv("NIF_XTY_LDS_PAD")) lds += (size_t)atoi(pad);  // tuning aid: caps workgroups per CU
   prof_begin(NIF_PROF_XTY, st);
-  if (in_dtype == NIF_F32 && acc == NIF_F32) {
+  if (flags & NIF_XTY_SPLIT_BF16) {
+    launch_split_bf16<2>(a, nblocks, lds, st);
+  } else if (in_dtype == NIF_F32 && acc == NIF_F32) {
     if (pl.f == 3) launch_variant<float, MmaF32, 3>(a, nblocks, lds, st);
     else launch_variant<float, MmaF32, 2>(a, nblocks, lds, st);
   } else if (in_dtype == NIF_F32) {

@@ -42,7 +42,7 @@ def _ld(t):
 
 
 def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, trans_b=False, norms=True,
-        rows_sharded=False):
+        rows_sharded=False, split_bf16=False):
     """G = A^T B over the rows (f64, n0 x n1) and the squared column norms (f64).
 
     rows_sharded=True marks a contraction over the fusion samples: inside a
@@ -50,6 +50,8 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
 
     A: m x n0, B: m x n1 (or n x m when trans_*).  B=None means B is A (symmetric mode).
     acc: 'f32' (exact-f32 MFMA per row block, f64 across blocks) or 'f64' (f64 MFMA).
+    split_bf16=True (f32 inputs, acc 'f32', no transposes): the products run as six bf16 matrix instructions
+    on the exact three-way bf16 split of every operand -- f32-level accuracy, different last bits.
     Returns (G, na, nb); na/nb are None when norms=False.
     """
     symmetric = B is None
@@ -69,7 +71,7 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
     accv = _lib.NIF_F64 if (acc == 'f64' or A.dtype == torch.float64) else _lib.NIF_F32
     flags = ((_lib.NIF_RELU_A if relu_a else 0) | (_lib.NIF_RELU_B if relu_b else 0) |
              (_lib.NIF_SYMMETRIC if symmetric else 0) | (_lib.NIF_TRANS_A if trans_a else 0) |
-             (_lib.NIF_TRANS_B if trans_b else 0))
+             (_lib.NIF_TRANS_B if trans_b else 0) | (_lib.NIF_XTY_SPLIT_BF16 if split_bf16 else 0))
     with torch.cuda.device(A.device):
         G = torch.empty((n0, n1), dtype=torch.float64, device=A.device)
         na = torch.empty(n0, dtype=torch.float64, device=A.device) if norms else None

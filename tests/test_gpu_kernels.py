@@ -490,3 +490,41 @@ def test_design_matrix_matches_unfold(ops, shape, k, stride, pad, ones):
     assert torch.equal(out.cpu(), ref)
     base = out.as_strided((out.shape[0], out.stride(0)), (out.stride(0), 1))  # pad columns are written as zeros
     assert (base[:, out.shape[1]:] == 0).all()
+
+
+@pytest.mark.parametrize('m,n0,n1,sym,relu', [(1000, 128, 256, False, False), (777, 132, 260, False, False),
+                                              (4096, 384, 384, False, True), (530, 200, 200, True, False),
+                                              (16, 128, 128, False, False), (5, 4, 8, False, False),
+                                              (20000, 384, 384, False, False), (3000, 520, 520, True, True)])
+def test_xty_split_bf16_matches_f64_gram(ops, m, n0, n1, sym, relu):
+    """The split-bf16 Gram (six bf16 matrix instructions on the exact three-way split of every f32 operand) is as
+    close to the exact Gram as the f32 matrix path: both are checked against the f64-accumulated result on ragged
+    tiles (columns not a multiple of 128, rows not a multiple of 16), symmetric mode and ReLU-on-load."""
+    g = torch.Generator().manual_seed(m + n0)
+    A = torch.randn(m, n0, generator=g).cuda()
+    B = None if sym else torch.randn(m, n1, generator=g).cuda()
+    kw = dict(relu_a=relu, relu_b=relu and not sym)
+    G, na, nb = ops.xty(A, B, split_bf16=True, **kw)
+    Ar = A.double().clamp_min(0) if relu else A.double()
+    Br = Ar if sym else (B.double().clamp_min(0) if relu else B.double())
+    ref = Ar.T @ Br
+    scale = ref.abs().max().item()
+    G32, _, _ = ops.xty(A, B, **kw)
+    err, err32 = (G - ref).abs().max().item() / scale, (G32 - ref).abs().max().item() / scale
+    assert err < 3e-6 and err < 4 * err32 + 1e-7, (err, err32)
+    assert torch.allclose(na, (Ar ** 2).sum(0), rtol=2e-6)
+    assert torch.allclose(nb, (Br ** 2).sum(0), rtol=2e-6)
+    if sym:
+        assert torch.equal(G, G.T)
+
+
+def test_xty_split_bf16_falls_back_when_rows_are_not_16_byte_pieces(ops):
+    """Operands the split kernel cannot address in 16-byte pieces (odd width) take the f32 matrix path: same bits."""
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(300, 131, generator=g).cuda()
+    B = torch.randn(300, 64, generator=g).cuda()
+    G0, na0, nb0 = ops.xty(A, B)
+    G1, na1, nb1 = ops.xty(A, B, split_bf16=True)
+    assert torch.equal(G0, G1) and torch.equal(na0, na1) and torch.equal(nb0, nb1)
+    with pytest.raises(Exception):
+        ops.xty(A, B, acc='f64', split_bf16=True)

@@ -11,10 +11,18 @@ for m, n, acc in shapes:
     A = torch.randn(m, n, device='cuda', generator=g)
     sym = acc == 'f64' or n >= 6144
     B = None if sym else torch.randn(m, n, device='cuda', generator=g)
-    for _ in range(2): ops.xty(A, B, acc=acc)
+    split = acc == 'f32' and os.environ.get('SPLIT') == '1'
+    for _ in range(2): out = ops.xty(A, B, acc=acc, split_bf16=split)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     it = 10
-    for _ in range(it): ops.xty(A, B, acc=acc)
+    for _ in range(it): ops.xty(A, B, acc=acc, split_bf16=split)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / it
     fl = m * n * (n + 1) if sym else 2.0 * m * n * n
-    print(f'm={m} n={n} {acc} sym={sym}: {dt * 1e3:.3f} ms ({fl / dt / 1e12:.1f} TF incl. reduction)', flush=True)
+    err = ''
+    if split and m * n <= 4e8:  # accuracy against the f64-accumulated Gram
+        ref = ops.xty(A, B, acc='f64')
+        f32 = ops.xty(A, B, acc='f32')
+        scale = ref[0].abs().max()
+        err = (f'; max err vs f64 / max|G|: split {((out[0] - ref[0]).abs().max() / scale).item():.2e}, '
+               f'f32 path {((f32[0] - ref[0]).abs().max() / scale).item():.2e}; norms {((out[1] - ref[1]).abs().max() / ref[1].abs().max()).item():.1e}')
+    print(f'm={m} n={n} {acc} sym={sym}: {dt * 1e3:.3f} ms ({fl / dt / 1e12:.1f} TF incl. reduction){err}', flush=True)
