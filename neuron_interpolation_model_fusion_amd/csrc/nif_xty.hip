@@ -470,9 +470,8 @@ __global__ __launch_bounds__(NT, (xty_waves_per_simd<MmaT, FI>())) void xty_kern
 // Data path: 16-byte global loads of the row-major f32 tile (a dword-per-lane load moves 16 B/clk/CU through the
 // texture addresser whatever its coalescing; only dwordx4 reaches 64 B/clk) -> split in registers -> three
 // row-major bf16 planes [16 samples][128 columns] in LDS -> ds_read_b64_tr_b16, the transposing read of gfx950,
-// hands every lane the 8 consecutive samples of its column that the 32x32x16 operand layout wants.  Rows of a
-// plane are 256 B; 16-byte chunk ch of row r sits at chunk ch ^ (((r & 3) << 2) | ((r >> 2) & 3)), which keeps the
-// transposed reads off each other's banks (cdna_hip_programming.md T10, image (b)).
+// hands every lane the 8 consecutive samples of its column that the 32x32x16 operand layout wants.  Plane rows
+// are padded by 64 B so that the four rows one transposed read gathers fall on different banks.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -499,18 +498,17 @@ __device__ __forceinline__ void fmac_f32(float& acc, float a, float b) {
   asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-__device__ __forceinline__ int bf16_plane_off(int row, int ch) {
-  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-}
-
 template <int FI, bool RELU_A, bool RELU_B>
-__global__ __launch_bounds__(NT, 2) void xty_bf16_kernel(const XtyArgs p) {
-  static_assert(FI == 2, "the split-bf16 kernel is written for 128-wide tiles");
-  constexpr int TM = 128;
-  constexpr int PLANE = BK * TM * 2;  // bytes of one split plane of one operand tile
-  constexpr int OPB = 3 * PLANE;      // one operand: hi, mid, lo
-  constexpr int BUFB = 2 * OPB;       // one buffer: A, B
-  typedef MmaF32<FI, FI> Acc;         // same 32x32 accumulator layout
+__global__ __launch_bounds__(NT, (FI == 3 ? 1 : 2)) void xty_bf16_kernel(const XtyArgs p) {
+  constexpr int TM = 64 * FI;
+  constexpr int PITCH = TM * 2 + 64;   // bytes per plane row: the pad keeps the four rows a transposed read
+                                       // gathers on different banks (pitch = 64 or 192 mod 256), no swizzle
+  constexpr int PLANE = BK * PITCH;    // one split plane of one operand tile: [16 samples][TM columns] bf16
+  constexpr int OPB = 3 * PLANE;       // one operand: hi, mid, lo
+  constexpr int BUFB = 2 * OPB;        // one buffer: A, B
+  constexpr int NP = TM / 64;          // 16-byte pieces per thread and operand tile
+  constexpr int RC4 = TM / 4;          // pieces per tile row
+  typedef MmaF32<FI, FI> Acc;          // same 32x32 accumulator layout
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -560,30 +558,36 @@ __global__ __launch_bounds__(NT, 2) void xty_bf16_kernel(const XtyArgs p) {
   const bool want_a = (p.flags & NIF_SYMMETRIC) ? (ti == tj) : (tj == 0);
   const bool want_b = !(p.flags & NIF_SYMMETRIC) && (ti == 0);
 
-  // Staging map: thread -> 16-byte piece (row srow + 8 h, columns 4 c4 .. + 3) of both operand tiles, h = 0, 1.
-  // Columns past the matrix edge re-read the last valid piece: the padded rows / columns of the slab then hold
-  // finite garbage that nothing reads, and the loop needs no guards.
-  const int srow = tid >> 5, c4 = tid & 31;
-  const int cola = min(ci + 4 * c4, p.n0 - 4), colb = min(cj + 4 * c4, p.n1 - 4);
-  unsigned goffa[2], goffb[2], woff[2];
+  // Staging map: piece q = tid + 256 h of a [16][TM] tile = row q / (TM/4), columns 4 (q % (TM/4)) .. + 3, the same
+  // for both operands.  Columns past the matrix edge re-read the last valid piece: the padded rows / columns of
+  // the slab then hold finite garbage that nothing reads, and the loop needs no guards.
+  unsigned goffa[NP], goffb[NP], woff[NP];
+  int prow[NP], pcol[NP];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    goffa[h] = (unsigned)(((srow + 8 * h) * p.lda + cola) * 4);
-    goffb[h] = (unsigned)(((srow + 8 * h) * p.ldb + colb) * 4);
-    woff[h] = (unsigned)(bf16_plane_off(srow + 8 * h, c4 >> 1) + 8 * (c4 & 1));
+  for (int h = 0; h < NP; ++h) {
+    const int q = tid + NT * h;
+    prow[h] = q / RC4;
+    pcol[h] = 4 * (q - prow[h] * RC4);
+    goffa[h] = (unsigned)((prow[h] * p.lda + min(ci + pcol[h], p.n0 - 4)) * 4);
+    goffb[h] = (unsigned)((prow[h] * p.ldb + min(cj + pcol[h], p.n1 - 4)) * 4);
+    woff[h] = (unsigned)(prow[h] * PITCH + pcol[h] * 2);
   }
   const char* rowa = reinterpret_cast<const char*>(A + k_begin * p.lda);  // scalar
   const char* rowb = reinterpret_cast<const char*>(B + k_begin * p.ldb);
   const int64_t tile_a = (int64_t)BK * p.lda * 4, tile_b = (int64_t)BK * p.ldb * 4;
-  float sqa[4] = {0.f, 0.f, 0.f, 0.f}, sqb[4] = {0.f, 0.f, 0.f, 0.f};
+  float sqa[NP][4], sqb[NP][4];
+#pragma unroll
+  for (int h = 0; h < NP; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sqa[h][e] = sqb[h][e] = 0.f;
 
   // full tile tt (samples k_begin + 16 tt .. + 15) -> registers.  The empty asm keeps the 32-bit offsets opaque
   // inside the loop: hoisted, their zero-extensions would turn the scalar-base addressing into 64-bit vector adds.
-  auto stage = [&](float4 (&x)[2][2], int tt) {
+  auto stage = [&](float4 (&x)[2][NP], int tt) {
     const char* ba = rowa + tt * tile_a;
     const char* bb = rowb + tt * tile_b;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NP; ++h) {
       unsigned oa = goffa[h], ob = goffb[h];
       asm volatile("" : "+v"(oa), "+v"(ob));
       x[0][h] = *reinterpret_cast<const float4*>(ba + oa);
@@ -591,13 +595,13 @@ __global__ __launch_bounds__(NT, 2) void xty_bf16_kernel(const XtyArgs p) {
     }
   };
   // the last, partial tile of the last split: rows guarded
-  auto stage_tail = [&](float4 (&x)[2][2], int tt) {
+  auto stage_tail = [&](float4 (&x)[2][NP], int tt) {
     const int64_t k0 = k_begin + (int64_t)tt * BK;
     const char* ba = rowa + tt * tile_a;
     const char* bb = rowb + tt * tile_b;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const bool rok = k0 + srow + 8 * h < k_end;
+    for (int h = 0; h < NP; ++h) {
+      const bool rok = k0 + prow[h] < k_end;
       x[0][h] = rok ? *reinterpret_cast<const float4*>(ba + goffa[h]) : make_float4(0.f, 0.f, 0.f, 0.f);
       x[1][h] = rok ? *reinterpret_cast<const float4*>(bb + goffb[h]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -623,35 +627,29 @@ __global__ __launch_bounds__(NT, 2) void xty_bf16_kernel(const XtyArgs p) {
       }
     }
   };
-  auto commit = [&](const float4 (&x)[2][2], int buf) {
+  auto commit = [&](const float4 (&x)[2][NP], int buf) {
     unsigned char* L = smem_raw + buf * BUFB;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      split_put(x[0][h], RELU_A, sqa, L + woff[h]);
-      split_put(x[1][h], RELU_B, sqb, L + OPB + woff[h]);
+    for (int h = 0; h < NP; ++h) {
+      split_put(x[0][h], RELU_A, sqa[h], L + woff[h]);
+      split_put(x[1][h], RELU_B, sqb[h], L + OPB + woff[h]);
     }
   };
 
-  // transposed-read addresses: lane (column l & 31 of a 32-wide fragment, k half l >> 5) takes rows
+  // transposed-read base addresses: lane (column l & 31 of a 32-wide fragment, k half l >> 5) takes rows
   // 8 (l >> 5) + 4 jj + 0..3; inside its 16-lane group, lane 4 q + pp supplies row q, columns 4 pp .. + 3.
-  unsigned ra[2][2], rb[2][2];  // [fragment][row block jj]
+  // Fragment i, row block jj, plane and buffer are immediates on top of one base per operand.
+  unsigned rbase_a, rbase_b;
   {
     const int kh = lane >> 5, g1 = (lane >> 4) & 1, l16 = lane & 15, q = l16 >> 2, pp = l16 & 3;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int row = 8 * kh + 4 * jj + q;
-        const int cha = (wi * 64 + 32 * i + 16 * g1) / 8 + (pp >> 1);
-        const int chb = (wj * 64 + 32 * i + 16 * g1) / 8 + (pp >> 1);
-        ra[i][jj] = (unsigned)(bf16_plane_off(row, cha) + 8 * (pp & 1));
-        rb[i][jj] = (unsigned)(OPB + bf16_plane_off(row, chb) + 8 * (pp & 1));
-      }
+    const int rowoff = (8 * kh + q) * PITCH + (16 * g1 + 4 * pp) * 2;
+    rbase_a = (unsigned)(rowoff + wi * (TM / 2) * 2);
+    rbase_b = (unsigned)(OPB + rowoff + wj * (TM / 2) * 2);
   }
-  auto frag8 = [&](int buf, const unsigned (&addr)[2], int sidx) -> bf16x8 {
-    const unsigned char* base = smem_raw + buf * BUFB + sidx * PLANE;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr[0]));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr[1]));
+  auto frag8 = [&](int buf, unsigned rbase, int i, int sidx) -> bf16x8 {
+    const unsigned char* base = smem_raw + rbase + buf * BUFB + sidx * PLANE + i * 64;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * PITCH));
     union {
       s16x8 s;
       bf16x8 v;
@@ -659,41 +657,44 @@ __global__ __launch_bounds__(NT, 2) void xty_bf16_kernel(const XtyArgs p) {
     u.s = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return u.v;
   };
-  // the 24 matrix instructions of one tile, term by term (smallest first) so that consecutive ones hit different
-  // accumulators; `mid` (the split of a later tile) is spread between them by the issue-order directives
+  // the 6 FI^2 matrix instructions of one tile, term by term (smallest first) so that consecutive ones hit
+  // different accumulators; `mid` (the split of a later tile) is spread between them by the issue-order directives
   auto mma_tile = [&](int buf, auto&& mid) {
-    const bf16x8 a00 = frag8(buf, ra[0], 0), a01 = frag8(buf, ra[1], 0), b00 = frag8(buf, rb[0], 0), b01 = frag8(buf, rb[1], 0);
-    const bf16x8 a20 = frag8(buf, ra[0], 2), a21 = frag8(buf, ra[1], 2), b20 = frag8(buf, rb[0], 2), b21 = frag8(buf, rb[1], 2);
-    const bf16x8 a10 = frag8(buf, ra[0], 1), a11 = frag8(buf, ra[1], 1), b10 = frag8(buf, rb[0], 1), b11 = frag8(buf, rb[1], 1);
-#define NIF_TERM(A0, A1, B0, B1)                                                            \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[0][0], 0, 0, 0);          \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc[0][1], 0, 0, 0);          \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc[1][0], 0, 0, 0);          \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0)
-    NIF_TERM(a20, a21, b00, b01);
-    mid();
-    NIF_TERM(a00, a01, b20, b21);
-    NIF_TERM(a10, a11, b10, b11);
-    NIF_TERM(a10, a11, b00, b01);
-    NIF_TERM(a00, a01, b10, b11);
-    NIF_TERM(a00, a01, b00, b01);
-#undef NIF_TERM
+    bf16x8 a[3][FI], b[3][FI];
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx)
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        a[sidx][i] = frag8(buf, rbase_a, i, sidx);
+        b[sidx][i] = frag8(buf, rbase_b, i, sidx);
+      }
+    constexpr int TA_[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int TB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+      if (term == 1) mid();
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA_[term]][i], b[TB_[term]][j], acc[i][j], 0, 0, 0);
+    }
     // Issue order inside this block: the split arithmetic of the next tile is spread through the matrix
     // instructions (a wave issues in order; a 32x32x16 instruction occupies the matrix pipe for 32 cycles but
-    // the issue port for 4, so a few vector instructions fit in its shadow) instead of sitting in one lump
+    // the issue port for 8, so a few vector instructions fit in its shadow) instead of sitting in one lump
     // during which the matrix pipe drains.
-    __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);  // the fragment reads first
+    __builtin_amdgcn_sched_group_barrier(0x100, 12 * FI, 0);  // the fragment reads first
 #pragma unroll
-    for (int q = 0; q < 24; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // five VALU
+    for (int q = 0; q < 6 * FI * FI; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, FI == 3 ? 4 : 5, 0);  // a few VALU
       if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // one LDS write
     }
   };
 
   // Two register sets: while tile t computes, tile t + 1 is committed from one set and tile t + 2 is in flight
   // into the other (a tile of bf16 matrix work is a quarter of the f32 kernel's: a distance of one is too short).
-  float4 xa[2][2], xb[2][2];
+  float4 xa[2][NP], xb[2][NP];
   if (ntf > 0) {
     stage(xa, 0);
     stage(xb, min(1, last));
@@ -726,20 +727,22 @@ __global__ __launch_bounds__(NT, 2) void xty_bf16_kernel(const XtyArgs p) {
   float* S = reinterpret_cast<float*>(p.slab) + ((int64_t)split * p.n0p + ci + wi * (TM / 2)) * p.n1p + cj + wj * (TM / 2);
   Acc::store(S, p.n1p, acc, lane);
 
-  // column-norm partials: the eight row groups of a column piece sit in eight threads
-  float* red = reinterpret_cast<float*>(smem_raw);  // [operand][row group][TM]; the tile images are dead
+  // column-norm partials: every (tile row, column) slot of the [16][TM] image belongs to one thread and piece
+  float* red = reinterpret_cast<float*>(smem_raw);  // [operand][16][TM]; the tile images are dead
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    red[srow * TM + 4 * c4 + e] = sqa[e];
-    red[(8 + srow) * TM + 4 * c4 + e] = sqb[e];
-  }
+  for (int h = 0; h < NP; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[prow[h] * TM + pcol[h] + e] = sqa[h][e];
+      red[(BK + prow[h]) * TM + pcol[h] + e] = sqb[h][e];
+    }
   __syncthreads();
   if (tid < TM) {
     float sa = 0.f, sb = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < BK; ++r) {
       sa += red[r * TM + tid];
-      sb += red[(8 + r) * TM + tid];
+      sb += red[(BK + r) * TM + tid];
     }
     if (want_a) reinterpret_cast<float*>(p.nslab_a)[(int64_t)split * p.n0p + ci + tid] = sa;
     if (want_b) reinterpret_cast<float*>(p.nslab_b)[(int64_t)split * p.n1p + cj + tid] = sb;
@@ -809,7 +812,7 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   // fill the chip (256 CUs x resident workgroups per CU) without leaving a second, nearly empty
   // round of workgroups; keep >= 4 K-tiles per row block
   const bool split_bf16 = (flags & NIF_XTY_SPLIT_BF16) != 0;
-  pl.slots = 256 * (f == 3 ? 2 : (in_f64 || acc == NIF_F64 || split_bf16 ? 2 : 4));
+  pl.slots = 256 * (split_bf16 ? (f == 3 ? 1 : 2) : (f == 3 ? 2 : (in_f64 || acc == NIF_F64 ? 2 : 4)));
   pl.slots /= slot_div;
   if (const char* e = getenv("NIF_XTY_SLOTS")) {  // tuning aid: workgroups the split-K aims for
     const int v = atoi(e);
@@ -835,7 +838,7 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   const size_t tiles = (size_t)2 * 2 * BK * (pl.tm + 16) * (in_f64 ? 8 : 4);
   const size_t red = (size_t)BK * pl.tm * esz;  // norm reduction scratch aliases the tile images
   pl.lds_bytes = tiles > red ? tiles : red;
-  if (split_bf16) pl.lds_bytes = (size_t)2 * 2 * 3 * BK * pl.tm * 2;  // [buf][operand][3 planes][16][tm] bf16
+  if (split_bf16) pl.lds_bytes = (size_t)2 * 2 * 3 * BK * (pl.tm * 2 + 64);  // [buf][operand][3 planes][16][tm + pad] bf16
   return pl;
 }
 
@@ -862,7 +865,10 @@ static XtyPlan make_plan(int64_t m, int n0, int n1, int in_f64, int acc, int fla
   double best_cost = 0.0;
   bool have = false;
   for (int f = 2; f <= 3; ++f) {
-    if (f == 3 && (acc != NIF_F32 || (flags & NIF_XTY_SPLIT_BF16))) continue;  // 192-wide tiles: f32 matrix path only
+    if (f == 3 && acc != NIF_F32) continue;  // the 192-wide tile exists for the f32-accumulate paths only
+    // split-bf16: the 192-wide instantiation compiles, but with one wave per SIMD the compiler shuttles the 144
+    // accumulator registers between the two register files every tile (0.76 ms against 0.55 at C2): 128 only
+    if (f == 3 && (flags & NIF_XTY_SPLIT_BF16) && forced != 3) continue;
     if ((forced == 2 || forced == 3) && f != forced) continue;
     for (int div = 1; div <= 4; div *= 2) {
       if (f == 3 && div == 4) continue;
@@ -985,7 +991,8 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
   if (const char* pad = getenv("NIF_XTY_LDS_PAD")) lds += (size_t)atoi(pad);  // tuning aid: caps workgroups per CU
   prof_begin(NIF_PROF_XTY, st);
   if (flags & NIF_XTY_SPLIT_BF16) {
-    launch_split_bf16<2>(a, nblocks, lds, st);
+    if (pl.f == 3) launch_split_bf16<3>(a, nblocks, lds, st);
+    else launch_split_bf16<2>(a, nblocks, lds, st);
   } else if (in_dtype == NIF_F32 && acc == NIF_F32) {
     if (pl.f == 3) launch_variant<float, MmaF32, 3>(a, nblocks, lds, st);
     else launch_variant<float, MmaF32, 2>(a, nblocks, lds, st);
