@@ -32,7 +32,15 @@ __global__ void lap_colmin_partial_kernel(const float* __restrict__ C, int64_t l
   int r1 = r0 + rows_per_chunk;
   if (r1 > n) r1 = n;
   float mn = INFINITY;
-  for (int r = r0; r < r1; ++r) mn = fminf(mn, C[(int64_t)r * ldc + j]);
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {  // eight independent loads in flight: the loop is latency-bound otherwise
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = C[(int64_t)(r + e) * ldc + j];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mn = fminf(mn, x[e]);
+  }
+  for (; r < r1; ++r) mn = fminf(mn, C[(int64_t)r * ldc + j]);
   part[(int64_t)blockIdx.y * n + j] = mn;
 }
 
@@ -151,8 +159,14 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
   }
 
   int step = 0;
-  for (int cur = 0; cur < n; ++cur) {
-    if (col4row[cur] != -1) continue;  // same LDS word for every thread: uniform
+  // free rows in ascending order, 64 at a time: one LDS read and a ballot per block of rows instead of a dependent
+  // LDS read per row (that scan alone took 17 us at n = 384).  A search matches only its own row, so the mask of a
+  // block stays valid while its rows are processed.
+  for (int rbase = 0; rbase < n; rbase += 64) {
+    unsigned long long freemask = __ballot(rbase + lane < n && col4row[rbase + lane] == -1);  // same in every wave
+    while (freemask) {
+    const int cur = rbase + __ffsll(freemask) - 1;
+    freemask &= freemask - 1;
 
     // per search: the columns of a lane keep their distance, scanned bit, matched row and tie-break key in
     // registers -- nothing of a Dijkstra step but the `path` store touches LDS before the reduction.
@@ -300,6 +314,7 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
       }
     }
     __syncthreads();
+    }
   }
 
 #pragma unroll
@@ -323,7 +338,7 @@ static inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static LapWs lap_ws(int n) {
   LapWs w;
-  w.chunks = (n + 63) / 64;
+  w.chunks = (n + 15) / 16;  // many short row chunks: the pass is latency-bound, not bandwidth-bound, at these sizes
   if (w.chunks > LAP_CHUNKS_MAX) w.chunks = LAP_CHUNKS_MAX;
   w.rows_per_chunk = (n + w.chunks - 1) / w.chunks;
   w.chunks = (n + w.rows_per_chunk - 1) / w.rows_per_chunk;

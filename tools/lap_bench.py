@@ -14,7 +14,7 @@ def t(fn, n=3):
 def steps(n):
     """Dijkstra steps of the last solve: the kernel leaves the count in the first word of the workspace's jbest area."""
     a256 = lambda x: (x + 255) & ~255
-    chunks = min((n + 63) // 64, 64)
+    chunks = min((n + 15) // 16, 64)
     rpc = (n + chunks - 1) // chunks
     chunks = (n + rpc - 1) // rpc
     off = a256(chunks * n * 4) + 2 * a256(n * 8)

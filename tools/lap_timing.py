@@ -13,7 +13,7 @@ for n in (128, 256, 512, 1024):
         ops.lap_solve(C, scipy_order=so); torch.cuda.synchronize()
         t0 = time.perf_counter(); ops.lap_solve(C, scipy_order=so); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
         a256 = lambda x: (x + 255) & ~255
-        chunks = min((n + 63) // 64, 64); rpc = (n + chunks - 1) // chunks; chunks = (n + rpc - 1) // rpc
+        chunks = min((n + 15) // 16, 64); rpc = (n + chunks - 1) // chunks; chunks = (n + rpc - 1) // rpc
         off = a256(chunks * n * 4) + 2 * a256(n * 8)
         st = ops.lap_solve.last_workspace[off:off + 28].view(torch.int32).cpu().tolist()
         steps = st[0]
