@@ -213,7 +213,7 @@ def main():
     out = run_levels(args.warmup)
     sync()
     ops.profile_collect(ops.PROF_XTY)
-    ops.profile_enable(True)
+    ops.profile_enable(True, slots=[ops.PROF_XTY])  # spans of the dominant kernel only: each costs dispatch gaps
     t0 = time.perf_counter()
     out = run_levels(args.steps)
     sync()

@@ -67,7 +67,7 @@ int nif_device_count(void);
 #define NIF_PROF_XTY 0
 #define NIF_PROF_LAP 1
 #define NIF_PROF_KMEANS 2
-void nif_profile_enable(int on);
+void nif_profile_enable(int on); /* bit s set: record spans of slot s; negative: every slot; 0: off */
 int nif_profile_collect(int slot, double* total_ms, int64_t* launches);
 
 /* ---------------------------------------------------------------------------

@@ -36,14 +36,14 @@ struct Span {
   hipEvent_t a, b;
 };
 std::mutex g_mu;
-bool g_enabled = false;
+unsigned g_enabled = 0;  // bit s: spans of slot s are recorded
 std::vector<Span> g_spans;
 hipEvent_t g_open[NIF_PROFILE_SLOTS];
 }  // namespace
 
 void prof_begin(int slot, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_enabled || slot < 0 || slot >= NIF_PROFILE_SLOTS) return;
+  if (slot < 0 || slot >= NIF_PROFILE_SLOTS || !((g_enabled >> slot) & 1)) return;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
   (void)hipEventRecord(e, st);
@@ -52,7 +52,7 @@ void prof_begin(int slot, hipStream_t st) {
 
 void prof_end(int slot, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_enabled || slot < 0 || slot >= NIF_PROFILE_SLOTS || !g_open[slot]) return;
+  if (slot < 0 || slot >= NIF_PROFILE_SLOTS || !((g_enabled >> slot) & 1) || !g_open[slot]) return;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
   (void)hipEventRecord(e, st);
@@ -63,7 +63,7 @@ void prof_end(int slot, hipStream_t st) {
 
 extern "C" void nif_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(nif::g_mu);
-  nif::g_enabled = on != 0;
+  nif::g_enabled = on < 0 ? ~0u : (unsigned)on;  // bit s = slot s; negative = every slot
 }
 
 extern "C" int nif_profile_collect(int slot, double* total_ms, int64_t* launches) {

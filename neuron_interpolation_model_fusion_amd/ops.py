@@ -172,8 +172,11 @@ def refit_gather(W0, W1, rowsrc=None, colsrc=None, alpha=1.0, beta=1.0, sp=1):
 PROF_XTY, PROF_LAP, PROF_KMEANS = 0, 1, 2
 
 
-def profile_enable(on=True):
-    lib.nif_profile_enable(1 if on else 0)
+def profile_enable(on=True, slots=None):
+    """Record HIP-event spans around the library's dominant kernels; slots: the PROF_* slots wanted (default all).
+    Every recorded span costs two event packets on the stream (~5 us of dispatch gap each)."""
+    mask = -1 if slots is None else sum(1 << s for s in slots)
+    lib.nif_profile_enable(mask if on else 0)
 
 
 def profile_collect(slot):
