@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace nif {
 
@@ -79,6 +80,13 @@ __device__ __forceinline__ double wave_min_f64(double x) {
     wlo = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll(m) - 1);
   }
   return ordered_to_f64(((unsigned long long)whi << 32) | wlo);
+}
+
+// Tuning aids read from the environment once per process (0 when unset): call sites keep them in a function-local
+// static, so the hot path pays nothing for them.
+static inline int env_int(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
 }
 
 // hipGetLastError() is per-thread state shared with every other HIP user in the process (torch's

@@ -403,10 +403,10 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   // cross-wave part no longer depends on the wave count, so as many waves as fit win (tools/lap_bench.py)
   int cpt = 1;
   while (cpt < 8 && (n + cpt - 1) / cpt > 1024) cpt *= 2;
-  if (const char* e = getenv("NIF_LAP_CPT")) {  // tuning aid
-    const int c = atoi(e);
-    if ((c == 1 || c == 2 || c == 4 || c == 8) && (n + c - 1) / c <= 1024) cpt = c;
-  }
+  static const int cpt_override = env_int("NIF_LAP_CPT");  // tuning aid
+  if ((cpt_override == 1 || cpt_override == 2 || cpt_override == 4 || cpt_override == 8) &&
+      (n + cpt_override - 1) / cpt_override <= 1024)
+    cpt = cpt_override;
   int threads = ((n + cpt - 1) / cpt + 63) / 64 * 64;
   if (threads > 1024) return NIF_ERR_UNSUPPORTED;
   const size_t lds = (size_t)((3 * n + 3) & ~3) * sizeof(int) + LAP_MBOX_TOTAL * sizeof(int);

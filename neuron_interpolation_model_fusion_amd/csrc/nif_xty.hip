@@ -814,10 +814,8 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   const bool split_bf16 = (flags & NIF_XTY_SPLIT_BF16) != 0;
   pl.slots = 256 * (split_bf16 ? (f == 3 ? 1 : 2) : (f == 3 ? 2 : (in_f64 || acc == NIF_F64 ? 2 : 4)));
   pl.slots /= slot_div;
-  if (const char* e = getenv("NIF_XTY_SLOTS")) {  // tuning aid: workgroups the split-K aims for
-    const int v = atoi(e);
-    if (v >= 1) pl.slots = v;
-  }
+  static const int slots_override = env_int("NIF_XTY_SLOTS");  // tuning aid: workgroups the split-K aims for
+  if (slots_override >= 1) pl.slots = slots_override;
   int64_t target = pl.slots;
   if (pl.ntiles > target) target = pl.ntiles;
   int64_t splits = target / pl.ntiles;
@@ -859,8 +857,7 @@ static double plan_cost(const XtyPlan& pl, int slot_div, bool f64_path, size_t e
 static XtyPlan make_plan(int64_t m, int n0, int n1, int in_f64, int acc, int flags) {
   const bool f64_path = in_f64 || acc != NIF_F32;
   const size_t esz = acc == NIF_F64 ? 8 : 4;
-  int forced = 0;
-  if (const char* f = getenv("NIF_XTY_FRAGS")) forced = atoi(f);  // tuning aid
+  static const int forced = env_int("NIF_XTY_FRAGS");  // tuning aid
   XtyPlan best{};
   double best_cost = 0.0;
   bool have = false;
@@ -988,7 +985,8 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
 
   const int nblocks = pl.ntiles * pl.splits;
   size_t lds = pl.lds_bytes;
-  if (const char* pad = getenv("NIF_XTY_LDS_PAD")) lds += (size_t)atoi(pad);  // tuning aid: caps workgroups per CU
+  static const int lds_pad = env_int("NIF_XTY_LDS_PAD");  // tuning aid: caps workgroups per CU
+  if (lds_pad > 0) lds += (size_t)lds_pad;
   prof_begin(NIF_PROF_XTY, st);
   if (flags & NIF_XTY_SPLIT_BF16) {
     if (pl.f == 3) launch_split_bf16<3>(a, nblocks, lds, st);
