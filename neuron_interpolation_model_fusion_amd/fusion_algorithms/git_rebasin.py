@@ -11,6 +11,7 @@ gather fused with the importance-weighted average (ops.refit_gather).
 import torch
 
 from .. import ops
+from ..models.base_model import twin_copy
 from ..utils.fusion_utils import (
     get_num_layers, initialize_activations, get_layer_weight, compute_neuron_importance_scores)
 
@@ -76,7 +77,8 @@ class GitRebasin:
         num_layers = get_num_layers([self.model0, self.model1])
         device = activations_dataset.device
         self._prepare_acts_based_alignment(activations_dataset, activations_labels, neuron_importance_method)
-        fused_hat = self.model0.copy_model().eval()
+        with twin_copy():
+            fused_hat = self.model0.copy_model().eval()
         self.permutations = []
 
         prev_is_conv, prev_col = False, None
@@ -131,4 +133,5 @@ class GitRebasin:
         self.model0.remove_hooks()
         self.model1.remove_hooks()
         fused_hat.remove_hooks()
-        return fused_hat.copy_model()
+        with twin_copy():
+            return fused_hat.copy_model()

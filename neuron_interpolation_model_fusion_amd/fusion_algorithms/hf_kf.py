@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from ..models.base_model import twin_copy
 from ..utils.fusion_utils import (
     get_num_layers, initialize_activations, get_layer_width, compute_neuron_importance_scores)
 from ..utils.model_utils import is_conv_weight
@@ -243,7 +244,8 @@ class LSFusion:
         for m in self.models:
             m.to(activation_dataset.device)
             initialize_activations(m, activation_dataset)
-        fused_hat = self.models[0].copy_model().eval()
+        with twin_copy():
+            fused_hat = self.models[0].copy_model().eval()
         self.last_layer_info = []
         for layer_idx in range(num_layers):
             print(f'Fusing layer {layer_idx + 1}/{num_layers}')
@@ -259,4 +261,5 @@ class LSFusion:
         for m in self.models:
             m.remove_hooks()
         fused_hat.remove_hooks()
-        return fused_hat.copy_model()
+        with twin_copy():
+            return fused_hat.copy_model()

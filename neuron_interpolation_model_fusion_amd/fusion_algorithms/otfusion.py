@@ -16,6 +16,7 @@ import time
 import torch
 
 from .. import ops
+from ..models.base_model import twin_copy
 from ..utils.fusion_utils import (
     get_num_layers, initialize_activations, get_layer_weight, get_layer_width, get_preactivations_of_layer,
     compute_neuron_importance_scores)
@@ -139,7 +140,8 @@ class OTFusion:
         mode = alignment_strategy['mode']
         num_layers = self._check_num_layers()
         input_dim = self._get_input_dim()
-        fused_hat = self.target_model.copy_model().eval()
+        with twin_copy():
+            fused_hat = self.target_model.copy_model().eval()
         dev = self.device
         use_scores = mode == 'acts' or alignment_strategy['wts']['neuron_importance_method'] != 'uniform'
         if use_scores:
@@ -242,5 +244,6 @@ class OTFusion:
                 model.remove_hooks()
             self.target_model.remove_hooks()
             fused_hat.remove_hooks()
-            fused_hat = fused_hat.copy_model()
+            with twin_copy():
+                fused_hat = fused_hat.copy_model()
         return fused_hat

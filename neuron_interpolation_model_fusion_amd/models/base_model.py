@@ -3,6 +3,7 @@
 The API is kept verbatim because it is the boundary of the hot path: the fusion
 algorithms only ever touch a model through the members defined here.
 """
+import contextlib
 from abc import ABC, abstractmethod
 from typing import NamedTuple
 
@@ -24,6 +25,35 @@ class LevelRepresentation(NamedTuple):
     name: str
     output_width: int
     network: nn.Module
+
+
+# copy_model() builds a fresh instance and loads the weights into it (models/vgg.py:120-125 ...): the random
+# initialisation of that instance is thrown away, yet it is most of the host time of a small fusion (27 of 69 ms for two
+# 784-8192-10 MLPs).  The matching algorithms draw nothing from torch's generator afterwards, so they construct their
+# copies under this context; ALF, whose batch order follows that generator, does not.  Set
+# `twin_copy.replay_init_draws = True` to consume the generator exactly as the reference does everywhere.
+_RANDOM_INITS = ('kaiming_uniform_', 'kaiming_normal_', 'uniform_', 'normal_', 'xavier_uniform_', 'xavier_normal_',
+                 'trunc_normal_')
+
+
+@contextlib.contextmanager
+def twin_copy():
+    """Context for copy_model() calls whose random initialisation is overwritten at once: the initialisers leave the
+    (uninitialised) storage alone and torch's generator is not advanced."""
+    if twin_copy.replay_init_draws:
+        yield
+        return
+    saved = {name: getattr(nn.init, name) for name in _RANDOM_INITS}
+    try:
+        for name in _RANDOM_INITS:
+            setattr(nn.init, name, lambda tensor, *args, **kwargs: tensor)
+        yield
+    finally:
+        for name, fn in saved.items():
+            setattr(nn.init, name, fn)
+
+
+twin_copy.replay_init_draws = False
 
 
 class BaseModel(nn.Module, ABC):

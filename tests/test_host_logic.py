@@ -100,3 +100,31 @@ def test_forward_level_walks_the_same_outputs_as_forward_until_level():
                 acts = model.forward_level(acts, level)
                 assert torch.equal(acts, model.forward_until_level(X, level)), (type(model).__name__, level)
             assert torch.equal(acts, model(X))
+
+
+def test_twin_copy_skips_the_discarded_random_init():
+    """copy_model() under twin_copy(): same weights, torch's generator untouched; with replay_init_draws the
+    generator advances exactly as a plain copy_model() (the reference's behaviour, models/mlp.py:46-53) does."""
+    import torch
+    from neuron_interpolation_model_fusion_amd.models import MLPNet
+    from neuron_interpolation_model_fusion_amd.models.base_model import twin_copy
+    torch.manual_seed(5)
+    m = MLPNet(20, 16, 4, use_bias=True, use_activations=False)
+    state = torch.get_rng_state()
+    with twin_copy():
+        c = m.copy_model()
+    assert torch.equal(torch.get_rng_state(), state)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+    assert torch.nn.init.kaiming_uniform_.__module__ == 'torch.nn.init'  # restored
+    plain = m.copy_model()
+    after_plain = torch.get_rng_state()
+    assert not torch.equal(after_plain, state)
+    torch.set_rng_state(state)
+    twin_copy.replay_init_draws = True
+    try:
+        with twin_copy():
+            m.copy_model()
+        assert torch.equal(torch.get_rng_state(), after_plain)
+    finally:
+        twin_copy.replay_init_draws = False
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), plain.state_dict().values()))
