@@ -19,7 +19,6 @@ import time
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from .. import ops
 from ..models.base_model import twin_copy

@@ -39,7 +39,8 @@ _RANDOM_INITS = ('kaiming_uniform_', 'kaiming_normal_', 'uniform_', 'normal_', '
 @contextlib.contextmanager
 def twin_copy():
     """Context for copy_model() calls whose random initialisation is overwritten at once: the initialisers leave the
-    (uninitialised) storage alone and torch's generator is not advanced."""
+    (uninitialised) storage alone and torch's generator is not advanced.  It swaps functions of torch.nn.init for
+    the duration of the block: not for use while another thread constructs modules."""
     if twin_copy.replay_init_draws:
         yield
         return
