@@ -143,9 +143,22 @@ int nif_cost_hf(const double* G01, int64_t ldg, const double* pp0, const double*
  */
 #define NIF_LAP_MAX_N 8192
 #define NIF_LAP_SCIPY_ORDER 1
+#define NIF_LAP_INIT_ONLY 2 /* fast mode, dual initialisation + greedy matching only: col4row[i] = -1 for rows left free
+                               (u, v, row4col required) */
+#define NIF_LAP_RESUME 4    /* fast mode, continue from the state an INIT_ONLY call left in u, v, col4row, row4col */
+#define NIF_LAP_BUDGET_SHIFT 8 /* fast mode: flags >> 8 = budget of Dijkstra steps (0 = none); once it is spent no
+                                  further row is started and the rows not reached keep col4row[i] = -1 */
 size_t nif_lap_workspace_bytes(int n);
 int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
                       double* u, double* v, void* ws, size_t ws_bytes, void* stream);
+
+/* Uniqueness certificate (no counterpart in the reference: it is what lets a call site that must reproduce
+ * scipy.optimize.linear_sum_assignment -- hf_kf.py:251, git_rebasin.py:112, alf.py:138,383 -- take the fast solver's
+ * answer): count[0] (device) = number of edges outside the matching whose reduced cost C[i][j] - u[i] - v[j] is
+ * <= tol_rel * (|C[i][j]| + |u[i]| + |v[j]|), plus matched edges that are not tight and unmatched rows.  0 means the
+ * optimal assignment is unique, so scipy returns the same one whatever its tie rule. */
+int nif_lap_count_tight_f32(const float* C, int64_t ldc, int n, const int32_t* col4row, const double* u, const double* v,
+                            double tol_rel, int32_t* count, void* stream);
 
 /* ---------------------------------------------------------------------------
  * nif_refit_gather: weight write-back under a matching,

@@ -19,6 +19,9 @@ NIF_F32, NIF_F64 = 0, 1
 NIF_RELU_A, NIF_RELU_B, NIF_SYMMETRIC, NIF_TRANS_A, NIF_TRANS_B, NIF_XTY_SPLIT_BF16 = 1, 2, 4, 8, 16, 32
 NIF_LAP_MAX_N = 8192
 NIF_LAP_SCIPY_ORDER = 1
+NIF_LAP_INIT_ONLY = 2
+NIF_LAP_RESUME = 4
+NIF_LAP_BUDGET_SHIFT = 8
 NIF_EMD_MAX_N = 8192
 NIF_EMD_EDGES_GLOBAL = 1
 NIF_ERR_WORKSPACE = -2
@@ -56,6 +59,7 @@ SIGNATURES = {
     'nif_wmse_workspace_bytes': (_sz, []),
     'nif_wmse_forward': (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _sz, _vp]),
     'nif_wmse_backward': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    'nif_lap_count_tight_f32': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _c.c_double, _vp, _vp]),
     'nif_im2row_f32': (_i32, [_vp, _i64] + [_i32] * 10 + [_vp, _i64, _vp]),
 }
 

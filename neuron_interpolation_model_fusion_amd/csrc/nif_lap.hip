@@ -121,7 +121,7 @@ template <int CPT, bool SCIPY>
 __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restrict__ C, int64_t ldc, int n,
                                                            double* __restrict__ u, double* __restrict__ vg,
                                                            int* __restrict__ col4row_g, int* __restrict__ row4col_g,
-                                                           int* __restrict__ stats) {
+                                                           int* __restrict__ stats, int max_steps) {
   extern __shared__ __attribute__((aligned(16))) int lap_sm[];
   int* path = lap_sm;
   int* row4col = lap_sm + n;
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
   for (int rbase = 0; rbase < n; rbase += 64) {
     unsigned long long freemask = __ballot(rbase + lane < n && col4row[rbase + lane] == -1);  // same in every wave
     while (freemask) {
+    // step budget (RESUME callers that only want cheap instances finished): the rows not reached stay free
+    if (max_steps > 0 && step >= max_steps) {  // uniform
+      rbase = n;
+      break;
+    }
     const int cur = rbase + __ffsll(freemask) - 1;
     freemask &= freemask - 1;
 
@@ -329,6 +334,35 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
   if (tid == 0) stats[0] = step;  // Dijkstra steps taken (work counter, read by tools/lap_bench.py)
 }
 
+// Uniqueness certificate for an optimal (col4row, u, v): counts the edges OUTSIDE the matching whose reduced cost
+// c_ij - u_i - v_j is not clearly positive (<= tol_rel * (|c_ij| + |u_i| + |v_j|); a negative one, i.e. infeasible
+// duals, counts too).  Zero such edges means no other assignment reaches the optimal cost, so every exact solver --
+// scipy's included -- returns this matching.  One wavefront per row, HBM-bound single pass over C.
+__global__ void lap_count_tight_kernel(const float* __restrict__ C, int64_t ldc, int n, const int* __restrict__ col4row,
+                                       const double* __restrict__ u, const double* __restrict__ v, double tol_rel,
+                                       int* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* row = C + (int64_t)i * ldc;
+  const double ui = u[i];
+  const int mate = col4row[i];
+  int bad = mate < 0 || mate >= n ? (lane == 0) : 0;  // an unmatched row is no certificate either
+  for (int j = lane; j < n; j += 64) {
+    const double c = (double)row[j], vj = v[j];
+    const double rc = c - ui - vj;
+    const double tol = tol_rel * (fabs(c) + fabs(ui) + fabs(vj));
+    if (j == mate) {
+      if (fabs(rc) > tol) ++bad;  // the matching must sit on tight edges
+    } else if (!(rc > tol)) {
+      ++bad;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if (lane == 0 && bad) atomicAdd(count, bad);
+}
+
 struct LapWs {
   size_t off_part, off_u, off_v, off_jbest, off_claim, off_r4c, total;
   int chunks, rows_per_chunk;
@@ -355,10 +389,10 @@ static LapWs lap_ws(int n) {
 
 template <int CPT, bool SCIPY>
 static void launch_augment(int threads, size_t lds, hipStream_t st, const float* C, int64_t ldc, int n, double* u,
-                           double* v, int* c4r, int* r4c, int* stats) {
+                           double* v, int* c4r, int* r4c, int* stats, int max_steps) {
   auto kfn = lap_augment_kernel<CPT, SCIPY>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(1), dim3(threads), lds, st, C, ldc, n, u, v, c4r, r4c, stats);
+  hipLaunchKernelGGL(kfn, dim3(1), dim3(threads), lds, st, C, ldc, n, u, v, c4r, r4c, stats, max_steps);
 }
 
 }  // namespace nif
@@ -387,7 +421,12 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
 
   const int nb = (n + 255) / 256;
   const bool scipy_order = (flags & NIF_LAP_SCIPY_ORDER) != 0;
-  if (scipy_order) {
+  const bool init_only = (flags & NIF_LAP_INIT_ONLY) != 0, resume = (flags & NIF_LAP_RESUME) != 0;
+  const int max_steps = (int)((unsigned)flags >> NIF_LAP_BUDGET_SHIFT);  // fast mode only; 0 = no budget
+  if ((init_only || resume) && (scipy_order || (init_only && resume) || !u || !v || !row4col)) return NIF_ERR_INVALID_ARG;
+  if (resume) {
+    // u, v, col4row, row4col hold the state an INIT_ONLY call left: go straight to the augmenting paths
+  } else if (scipy_order) {
     hipLaunchKernelGGL(lap_zero_init_kernel, dim3(nb), dim3(256), 0, st, n, uu, vv, col4row, r4c);
   } else {
   hipLaunchKernelGGL(lap_colmin_partial_kernel, dim3(nb, w.chunks), dim3(256), 0, st, C, ldc, n, w.rows_per_chunk,
@@ -397,6 +436,7 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   hipLaunchKernelGGL(lap_greedy_finish_kernel, dim3(nb), dim3(256), 0, st, n, jbest, claim, col4row, r4c);
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
+  if (init_only) return NIF_OK;
 
   // columns per lane: a Dijkstra step is a chain of dependent latencies (cost row -> relax -> wave minima ->
   // mailbox + barrier -> row-of-16 minima); the relax part grows with the columns a lane owns while the
@@ -413,8 +453,8 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   prof_begin(NIF_PROF_LAP, st);
 #define NIF_LAP_GO(CPT)                                                                       \
   do {                                                                                        \
-    if (scipy_order) launch_augment<CPT, true>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest); \
-    else launch_augment<CPT, false>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest);       \
+    if (scipy_order) launch_augment<CPT, true>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, 0); \
+    else launch_augment<CPT, false>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, max_steps);       \
   } while (0)
   switch (cpt) {
     case 1: NIF_LAP_GO(1); break;
@@ -424,5 +464,16 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   }
 #undef NIF_LAP_GO
   prof_end(NIF_PROF_LAP, st);
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+}
+
+extern "C" int nif_lap_count_tight_f32(const float* C, int64_t ldc, int n, const int32_t* col4row, const double* u,
+                                       const double* v, double tol_rel, int32_t* count, void* stream) {
+  using namespace nif;
+  if (!C || !col4row || !u || !v || !count || n <= 0 || ldc < n || !(tol_rel >= 0.0)) return NIF_ERR_INVALID_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  clear_err();
+  if (hipMemsetAsync(count, 0, sizeof(int32_t), st) != hipSuccess) return NIF_ERR_LAUNCH;
+  hipLaunchKernelGGL(lap_count_tight_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, ldc, n, col4row, u, v, tol_rel, count);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }

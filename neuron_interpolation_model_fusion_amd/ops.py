@@ -112,13 +112,21 @@ def cost_hf(G01, pp0, pp1, r0, r1, s0, s1):
     return C
 
 
+LAP_CERT_TOL = 1e-9  # relative reduced-cost margin below which a non-matching edge counts as a possible tie
+
+
 def lap_solve(C, duals=False, scipy_order=False):
     """Min-cost perfect matching of a square f32 cost matrix on the device.
 
-    Returns col4row (int32, device) -- scipy's ``col_ind`` -- and, with duals=True,
-    also (row4col, u, v).  scipy_order=True replays scipy's augmentation order and tie rule
-    (NIF_LAP_SCIPY_ORDER): same matching as scipy.optimize.linear_sum_assignment even when the
-    optimum is not unique because of exact structural ties; slower.
+    Returns col4row (int32, device) -- scipy's ``col_ind`` -- and, with duals=True, also (row4col, u, v).
+
+    scipy_order=True: the matching scipy.optimize.linear_sum_assignment returns, also when the optimum is not unique
+    because of exact structural ties.  Where the parallel dual initialisation already matches most rows (trained or
+    planted models) the fast solver finishes the problem and a certificate pass checks that no edge outside the
+    matching is tight (``nif_lap_count_tight_f32``): the optimum is then unique and scipy's answer is this one.
+    Otherwise -- random-initialised networks with dead units are ambiguous almost everywhere -- the kernel that
+    replays scipy's augmentation order and tie rule (NIF_LAP_SCIPY_ORDER) runs.  scipy_order='replay' forces that
+    kernel.  ``lap_solve.last_path`` names the path taken ('fast', 'certified', 'replay').
     """
     _need_gpu(C)
     C = _mat(C, 'C')
@@ -129,14 +137,39 @@ def lap_solve(C, duals=False, scipy_order=False):
         raise _lib.NifError(f'lap_solve: n={n} exceeds NIF_LAP_MAX_N={_lib.NIF_LAP_MAX_N}')
     with torch.cuda.device(C.device):
         col = torch.empty(n, dtype=torch.int32, device=C.device)
-        row = torch.empty(n, dtype=torch.int32, device=C.device) if duals else None
-        u = torch.empty(n, dtype=torch.float64, device=C.device) if duals else None
-        v = torch.empty(n, dtype=torch.float64, device=C.device) if duals else None
+        row = torch.empty(n, dtype=torch.int32, device=C.device)
+        u = torch.empty(n, dtype=torch.float64, device=C.device)
+        v = torch.empty(n, dtype=torch.float64, device=C.device)
         nbytes = lib.nif_lap_workspace_bytes(n)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=C.device)
         lap_solve.last_workspace = ws  # tools read the kernel's step counter out of it
-        check(lib.nif_lap_solve_f32(_ptr(C), _ld(C), n, _lib.NIF_LAP_SCIPY_ORDER if scipy_order else 0, _ptr(col), _ptr(row), _ptr(u), _ptr(v), _ptr(ws), nbytes,
-                                    _stream()), 'nif_lap_solve_f32')
+
+        def run(flags):
+            check(lib.nif_lap_solve_f32(_ptr(C), _ld(C), n, flags, _ptr(col), _ptr(row), _ptr(u), _ptr(v), _ptr(ws),
+                                        nbytes, _stream()), 'nif_lap_solve_f32')
+
+        path = 'fast'
+        if scipy_order is True and n >= 32:
+            path = 'replay'
+            run(_lib.NIF_LAP_INIT_ONLY)
+            free = int((col < 0).sum().item())
+            if free * 8 <= n:  # nearly solved by the dual initialisation
+                # a budget of Dijkstra steps keeps a hard instance from being solved twice: what the budget leaves
+                # unmatched fails the certificate
+                run(_lib.NIF_LAP_RESUME | ((16 * free + 64) << _lib.NIF_LAP_BUDGET_SHIFT))
+                cnt = torch.empty(1, dtype=torch.int32, device=C.device)
+                check(lib.nif_lap_count_tight_f32(_ptr(C), _ld(C), n, _ptr(col), _ptr(u), _ptr(v), LAP_CERT_TOL,
+                                                  _ptr(cnt), _stream()), 'nif_lap_count_tight_f32')
+                if int(cnt.item()) == 0:
+                    path = 'certified'
+            if path == 'replay':
+                run(_lib.NIF_LAP_SCIPY_ORDER)
+        elif scipy_order:
+            path = 'replay'
+            run(_lib.NIF_LAP_SCIPY_ORDER)
+        else:
+            run(0)
+        lap_solve.last_path = path
     if duals:
         return col, row, u, v
     return col

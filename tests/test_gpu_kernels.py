@@ -216,8 +216,60 @@ def test_lap_scipy_order_reproduces_scipy_under_ties(ops, n):
         cases.append(C2)
     cases.append(C)
     for Cx in cases:
-        col, ref = _check_lap(ops, Cx, scipy_order=True)
-        assert (col == ref).all()
+        for mode in (True, 'replay'):  # adaptive (certificate or replay) and the replay kernel itself
+            col, ref = _check_lap(ops, Cx, scipy_order=mode)
+            assert (col == ref).all()
+
+
+@pytest.mark.parametrize('n', [40, 384, 1500])
+def test_lap_scipy_order_takes_the_certified_fast_path_on_planted_instances(ops, n):
+    """A planted matching with noise (trained / permuted models): the dual initialisation matches nearly every row,
+    the certificate finds no tight edge outside the matching, and the answer -- scipy's own -- comes from the fast
+    solver.  Duplicating a column afterwards makes the optimum ambiguous: the certificate must see it and the
+    replay kernel must run."""
+    g = torch.Generator().manual_seed(7 + n)
+    A = torch.randn(600, n, generator=g)
+    perm = torch.randperm(n, generator=g)
+    B = A[:, perm] + 0.2 * torch.randn(600, n, generator=g)
+    C = torch.cdist(A.T, B.T)
+    col, ref = _check_lap(ops, C, scipy_order=True)
+    assert ops.lap_solve.last_path == 'certified'
+    assert (col == ref).all()
+    colr, _ = _check_lap(ops, C, scipy_order='replay')
+    assert (colr == col).all()
+    C2 = C.clone()
+    C2[:, 1] = C2[:, 0]
+    C2[2, :] = C2[3, :]
+    col2, ref2 = _check_lap(ops, C2, scipy_order=True)
+    assert ops.lap_solve.last_path == 'replay'
+    assert (col2 == ref2).all()
+    # a unique optimum the initialisation does not nearly solve goes to the replay kernel without a fast attempt
+    Cr = torch.rand(n, n, generator=g)
+    col3, ref3 = _check_lap(ops, Cr, scipy_order=True)
+    assert (col3 == ref3).all()
+
+
+def test_lap_certificate_counts_tight_edges(ops):
+    from neuron_interpolation_model_fusion_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    n = 96
+    C = torch.rand(n, n, generator=g).cuda()
+    col, row, u, v = ops.lap_solve(C, duals=True)
+    cnt = torch.empty(1, dtype=torch.int32, device='cuda')
+
+    def count(Cm, colm):
+        _lib.check(_lib.lib.nif_lap_count_tight_f32(Cm.data_ptr(), Cm.stride(0), n, colm.data_ptr(), u.data_ptr(), v.data_ptr(),
+                                                    1e-9, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   'nif_lap_count_tight_f32')
+        return int(cnt.item())
+
+    slack = (C.double() - u[:, None] - v[None, :])
+    slack[torch.arange(n), col.long()] = 1.0
+    expected = int((slack <= 1e-9 * (C.double().abs() + u.abs()[:, None] + v.abs()[None, :])).sum())
+    assert count(C, col) == expected
+    # a matching that is not on tight edges is flagged
+    wrong = col.roll(1)
+    assert count(C, wrong) > expected
 
 
 @pytest.mark.parametrize('shape', [(37, 10), (5, 7, 3, 3), (4, 16, 17), (64, 384, 65), (256, 64, 8, 8), (1, 1)])

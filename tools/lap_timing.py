@@ -10,8 +10,8 @@ for n in (128, 256, 512, 1024):
     G, na, nb = ops.xty(A, B)
     C = ops.cost_dist(G, na, nb)
     for so in (True,):
-        ops.lap_solve(C, scipy_order=so); torch.cuda.synchronize()
-        t0 = time.perf_counter(); ops.lap_solve(C, scipy_order=so); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
+        ops.lap_solve(C, scipy_order='replay' if so else False); torch.cuda.synchronize()
+        t0 = time.perf_counter(); ops.lap_solve(C, scipy_order='replay' if so else False); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
         a256 = lambda x: (x + 255) & ~255
         chunks = min((n + 15) // 16, 64); rpc = (n + chunks - 1) // chunks; chunks = (n + rpc - 1) // rpc
         off = a256(chunks * n * 4) + 2 * a256(n * 8)
