@@ -155,7 +155,8 @@ int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* co
 /* Uniqueness certificate (no counterpart in the reference: it is what lets a call site that must reproduce
  * scipy.optimize.linear_sum_assignment -- hf_kf.py:251, git_rebasin.py:112, alf.py:138,383 -- take the fast solver's
  * answer): count[0] (device) = number of edges outside the matching whose reduced cost C[i][j] - u[i] - v[j] is
- * <= tol_rel * (|C[i][j]| + |u[i]| + |v[j]|), plus matched edges that are not tight and unmatched rows.  0 means the
+ * <= tol_rel * (|C[i][j]| + |u[i]| + |v[j]|), plus matched edges that are not tight to 1e-5 of that margin and
+ * unmatched rows.  0 means the
  * optimal assignment is unique, so scipy returns the same one whatever its tie rule. */
 int nif_lap_count_tight_f32(const float* C, int64_t ldc, int n, const int32_t* col4row, const double* u, const double* v,
                             double tol_rel, int32_t* count, void* stream);

@@ -353,7 +353,9 @@ __global__ void lap_count_tight_kernel(const float* __restrict__ C, int64_t ldc,
     const double rc = c - ui - vj;
     const double tol = tol_rel * (fabs(c) + fabs(ui) + fabs(vj));
     if (j == mate) {
-      if (fabs(rc) > tol) ++bad;  // the matching must sit on tight edges
+      // the matching must sit on tight edges, and tighter than the margin by more than a factor n: any other
+      // assignment then costs more by at least one margin minus the sum of these residues
+      if (fabs(rc) > 1e-5 * tol) ++bad;
     } else if (!(rc > tol)) {
       ++bad;
     }

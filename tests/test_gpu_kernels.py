@@ -264,6 +264,7 @@ def test_lap_certificate_counts_tight_edges(ops):
         return int(cnt.item())
 
     slack = (C.double() - u[:, None] - v[None, :])
+    assert slack[torch.arange(n), col.long()].abs().max() < 1e-14
     slack[torch.arange(n), col.long()] = 1.0
     expected = int((slack <= 1e-9 * (C.double().abs() + u.abs()[:, None] + v.abs()[None, :])).sum())
     assert count(C, col) == expected
