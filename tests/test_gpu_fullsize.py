@@ -1,0 +1,134 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (no CPU oracle can run these sizes in
+seconds): split-K additivity and linearity of the Gram kernel, planted matchings recovered with their dual /
+uniqueness certificates, k-means monotonicity and target centroids, symmetric-Gram identities."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from neuron_interpolation_model_fusion_amd import ops as o
+    return o
+
+
+def _planted(m, n, seed, noise=0.3):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    A = torch.randn(m, n, device='cuda', generator=g)
+    perm = torch.randperm(n, device='cuda', generator=g)
+    B = 0.9 * A[:, perm] + noise * torch.randn(m, n, device='cuda', generator=g)
+    return A, B, perm
+
+
+def test_c2_level_at_full_size(ops):
+    """C2: m = 5000 x 65 rows, n = 384 (OTFusion activation-mode level)."""
+    m, n = 325000, 384
+    A, B, perm = _planted(m, n, 1)
+    G, na, nb = ops.xty(A, B)
+    # additivity over the contraction axis: the Gram of the whole = sum of the Grams of two row shards
+    h = 162500 + 37
+    G1, na1, nb1 = ops.xty(A[:h], B[:h])
+    G2, na2, nb2 = ops.xty(A[h:], B[h:])
+    scale = G.abs().max()
+    assert ((G1 + G2) - G).abs().max() / scale < 2e-6
+    assert torch.allclose(na1 + na2, na, rtol=1e-6) and torch.allclose(nb1 + nb2, nb, rtol=1e-6)
+    # bilinearity against an f64 matrix-vector identity: x^T G y = <A x, B y>
+    g = torch.Generator(device='cuda').manual_seed(2)
+    x = torch.randn(n, device='cuda', dtype=torch.float64, generator=g)
+    y = torch.randn(n, device='cuda', dtype=torch.float64, generator=g)
+    lhs = x @ G @ y
+    rhs = (A.double() @ x) @ (B.double() @ y)
+    assert abs(lhs - rhs) / (x.norm() * y.norm() * scale) < 1e-6
+    # the split-bf16 path: same Gram to f32 accuracy, same matching
+    Gs, nas, nbs = ops.xty(A, B, split_bf16=True)
+    assert (Gs - G).abs().max() / scale < 4e-6
+    C = ops.cost_dist(G, na, nb)
+    col, row, u, v = ops.lap_solve(C, duals=True)
+    # model-k unit i is target unit perm^-1[i] plus noise
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(n, device='cuda')
+    assert torch.equal(col.long(), inv)
+    assert torch.equal(ops.lap_solve(ops.cost_dist(Gs, nas, nbs)).long(), inv)
+    # dual certificate at full size
+    slack = C.double() - u[:, None] - v[None, :]
+    assert slack.min() > -1e-9 * C.abs().max()
+    assert slack[torch.arange(n, device='cuda'), col.long()].abs().max() < 1e-9 * C.abs().max()
+    # refit: gathering model k's rows / columns by the plan and averaging with itself is the identity on the target
+    W = torch.randn(n, n, device='cuda', generator=g)
+    prev = torch.arange(n, device='cuda', dtype=torch.int32)
+    out = ops.refit_gather(W, W[inv][:, :], rowsrc=row, colsrc=prev, alpha=0.5, beta=0.5)
+    assert torch.allclose(out, 0.5 * W + 0.5 * W[inv][row.long()], rtol=0, atol=0)
+
+
+def test_c3_assignment_at_full_size(ops):
+    """C3: Git Re-Basin cost of two 8192-wide layers, B = 4096: the scipy-order call site takes the certified path."""
+    m, n = 4096, 8192
+    g = torch.Generator(device='cuda').manual_seed(3)
+    A = torch.randn(m, n, device='cuda', generator=g).clamp_min(0)
+    perm = torch.randperm(n, device='cuda', generator=g)
+    B = 0.9 * A[:, perm] + 0.3 * torch.randn(m, n, device='cuda', generator=g)
+    G, na, nb = ops.xty(A, B, relu_a=True, relu_b=True)
+    C = ops.cost_dist(G, na, nb)
+    col, row, u, v = ops.lap_solve(C, duals=True, scipy_order=True)
+    assert ops.lap_solve.last_path == 'certified'
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(n, device='cuda')
+    assert torch.equal(col.long(), inv)
+    assert torch.equal(row.long()[col.long()], torch.arange(n, device='cuda'))
+    # the replay kernel (scipy's own order) agrees, as it must when the optimum is unique
+    assert torch.equal(ops.lap_solve(C, scipy_order='replay'), col)
+    # row-wise dual feasibility without materialising n^2 f64 twice
+    worst = 0.0
+    for r0 in range(0, n, 1024):
+        s = C[r0:r0 + 1024].double() - u[r0:r0 + 1024, None] - v[None, :]
+        worst = min(worst, float(s.min()))
+    assert worst > -1e-9 * float(C.abs().max())
+
+
+def test_c4_kmeans_at_full_size(ops):
+    """C4: ALF k-means of two ViT levels: m = 325 000 rows, N = 768 neurons, k = 384 clusters."""
+    m, h = 325000, 384
+    A0, A1, _ = _planted(m, h, 5, noise=0.5)
+    A = torch.cat([A0, A1], dim=1).contiguous()
+    N, k = 2 * h, h
+    G, na, _ = ops.xty(A, None)
+    assert torch.equal(G, G.T)
+    assert torch.allclose(G.diagonal(), na, rtol=1e-6)
+    s = torch.ones(N, device='cuda')
+    km = ops.KMeans(G, na, s, k)
+    assign = km.assign_to_neurons(0)  # centroids start at model 0's neurons (alf.py:216-226)
+    costs = []
+    for _ in range(6):
+        assign, nearest, cost, kprime = km.lloyd_step(assign)
+        costs.append(float(cost))
+    assert all(b <= a * (1 + 1e-9) for a, b in zip(costs, costs[1:])), costs  # Lloyd never increases the objective
+    lab = assign.long()
+    assert int(lab.min()) >= 0 and int(lab.max()) < k
+    T, kp = km.targets(A, assign)
+    # spot check: a target column is the (uniformly weighted) mean of its cluster's member columns
+    present = torch.unique(lab)
+    assert int(kp) == present.numel()
+    for idx in (0, present.numel() // 2, present.numel() - 1):
+        members = (lab == present[idx]).nonzero().squeeze(1)
+        ref = A[:, members].double().mean(dim=1)
+        assert torch.allclose(T[:, idx].double(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_c5_symmetric_gram_shard(ops):
+    """C5: one rank's share (25 000 of 200 000 rows) of the 8-model Gram at width 768: N = 6144."""
+    m, N = 25000, 6144
+    g = torch.Generator(device='cuda').manual_seed(9)
+    A = torch.randn(m, N, device='cuda', generator=g)
+    G, na, _ = ops.xty(A, None)
+    assert torch.equal(G, G.T)
+    # 1176 tiles already fill the chip, so the rows are not split: one f32 accumulation chain of 25 000 terms per
+    # entry (the reference's own f32 matmul is no better): sqrt(m) * eps_f32 ~ 1e-5
+    assert torch.allclose(G.diagonal(), na, rtol=2e-5)
+    x = torch.randn(N, device='cuda', dtype=torch.float64, generator=g)
+    quad = x @ G @ x
+    ref = (A.double() @ x).pow(2).sum()
+    assert abs(quad - ref) / ref < 1e-5  # x^T (A^T A) x = ||A x||^2, and positive
+    # the packed upper triangle used by the sharded all-reduce restores the matrix exactly
+    from neuron_interpolation_model_fusion_amd.parallel import pack_gram_upper, unpack_gram_upper
+    G2, na2 = unpack_gram_upper(pack_gram_upper(G, na), N)
+    assert torch.equal(G2, G) and torch.equal(na2, na)
