@@ -947,7 +947,8 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
                        int acc, int flags, double* G, int64_t ldg, double* na, double* nb, void* ws, size_t ws_bytes,
                        void* stream) {
   using namespace nif;
-  if (!A || !B || !G || m < 0 || n0 <= 0 || n1 <= 0 || ldg < n1) return NIF_ERR_INVALID_ARG;
+  // m == 0 (an empty shard): the operand pointers are never dereferenced and may be null
+  if ((m > 0 && (!A || !B)) || !G || m < 0 || n0 <= 0 || n1 <= 0 || ldg < n1) return NIF_ERR_INVALID_ARG;
   if (in_dtype != NIF_F32 && in_dtype != NIF_F64) return NIF_ERR_INVALID_ARG;
   if (acc != NIF_F32 && acc != NIF_F64) return NIF_ERR_INVALID_ARG;
   if (in_dtype == NIF_F64 && acc != NIF_F64) return NIF_ERR_INVALID_ARG;

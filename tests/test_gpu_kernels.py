@@ -581,3 +581,14 @@ def test_xty_split_bf16_falls_back_when_rows_are_not_16_byte_pieces(ops):
     assert torch.equal(G0, G1) and torch.equal(na0, na1) and torch.equal(nb0, nb1)
     with pytest.raises(Exception):
         ops.xty(A, B, acc='f64', split_bf16=True)
+
+
+@pytest.mark.parametrize('split', [False, True])
+def test_xty_empty_contraction_axis(ops, split):
+    """No fusion samples at all (an empty shard of a sharded run): the Gram and the norms are exact zeros."""
+    A = torch.empty(0, 12, device='cuda')
+    B = torch.empty(0, 20, device='cuda')
+    G, na, nb = ops.xty(A, B, split_bf16=split)
+    assert G.shape == (12, 20) and not G.any() and not na.any() and not nb.any()
+    Gs, nas, _ = ops.xty(A, None, acc='f64')
+    assert Gs.shape == (12, 12) and not Gs.any() and not nas.any()
