@@ -221,6 +221,10 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
     for (int i = 0; i < n0; ++i) {
       double s = a[i];
       const int j = jbest[i];
+      if (j < 0 || j >= n1) {  // a cost row without a finite entry has no tight arc
+        sup[i] = s > tol ? s : 0.0;
+        continue;
+      }
       const double d = dem[j];
       const double x = fmin(s, d);
       if (x > tol && arc_new(i, j, x)) {

@@ -80,9 +80,11 @@ __global__ void lap_rowmin_kernel(const float* __restrict__ C, int64_t ldc, int 
     }
   }
   if (lane == 0) {
-    u[i] = bv;
+    // a row without a single finite entry (bj still INT_MAX) claims nothing: it stays free and the augmenting
+    // phase reports it unmatched
+    u[i] = bj == INT_MAX ? 0.0 : bv;
     jbest[i] = bj;
-    atomicMin(&claim[bj], i);
+    if (bj != INT_MAX) atomicMin(&claim[bj], i);
   }
 }
 
@@ -91,7 +93,7 @@ __global__ void lap_greedy_finish_kernel(int n, const int* __restrict__ jbest, c
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int jb = jbest[t];
-  col4row[t] = (claim[jb] == t) ? jb : -1;
+  col4row[t] = (jb != INT_MAX && claim[jb] == t) ? jb : -1;
   const int c = claim[t];
   row4col[t] = (c == INT_MAX) ? -1 : c;
 }

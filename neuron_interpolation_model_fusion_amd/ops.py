@@ -149,6 +149,9 @@ def lap_solve(C, duals=False, scipy_order=False):
                                         nbytes, _stream()), 'nif_lap_solve_f32')
 
         path = 'fast'
+        if scipy_order and bool((torch.isnan(C) | (C == float('-inf'))).any()):
+            # scipy.optimize.linear_sum_assignment refuses these before it starts
+            raise ValueError('matrix contains invalid numeric entries')
         if scipy_order is True and n >= 32:
             path = 'replay'
             run(_lib.NIF_LAP_INIT_ONLY)
@@ -170,6 +173,9 @@ def lap_solve(C, duals=False, scipy_order=False):
         else:
             run(0)
         lap_solve.last_path = path
+        if scipy_order and path == 'replay' and bool((col < 0).any()):
+            # rows whose finite entries cannot all be matched stay free; scipy raises here too
+            raise ValueError('cost matrix is infeasible')
     if duals:
         return col, row, u, v
     return col

@@ -592,3 +592,21 @@ def test_xty_empty_contraction_axis(ops, split):
     assert G.shape == (12, 20) and not G.any() and not na.any() and not nb.any()
     Gs, nas, _ = ops.xty(A, None, acc='f64')
     assert Gs.shape == (12, 12) and not Gs.any() and not nas.any()
+
+
+def test_lap_scipy_order_rejects_invalid_costs_like_scipy(ops):
+    """scipy.optimize.linear_sum_assignment raises ValueError on NaN entries and on infeasible (all-infinite)
+    problems; the call sites that stand in for it do the same instead of returning a partial matching."""
+    C = torch.rand(40, 40)
+    bad = C.clone()
+    bad[3, :] = float('inf')
+    with pytest.raises(ValueError):
+        linear_sum_assignment(bad.numpy())
+    with pytest.raises(ValueError):
+        ops.lap_solve(bad.cuda(), scipy_order=True)
+    nan = C.clone()
+    nan[5, 7] = float('nan')
+    with pytest.raises(ValueError):
+        linear_sum_assignment(nan.numpy())
+    with pytest.raises(ValueError):
+        ops.lap_solve(nan.cuda(), scipy_order=True)
