@@ -23,7 +23,8 @@ __global__ void refit_gather_kernel(const float* __restrict__ W0, const float* _
   const int ci = colsrc ? colsrc[c] : c;
   const float a = alpha_v ? alpha_v[i] : alpha;
   const float b = beta_v ? beta_v[i] : beta;
-  const float w1 = W1[(int64_t)ri * width + (int64_t)ci * sp + e];
+  // -1 = a unit the assignment left unmatched (non-finite costs): contributes nothing instead of reading out of bounds
+  const float w1 = (ri < 0 || ci < 0) ? 0.f : W1[(int64_t)ri * width + (int64_t)ci * sp + e];
   const float w0 = W0 ? W0[(int64_t)i * width + x] : 0.f;
   out[(int64_t)i * width + x] = a * w0 + b * w1;
 }
@@ -43,7 +44,8 @@ __global__ void refit_pairs_kernel(const double* __restrict__ W, int64_t ldw, co
     float a = 0.f, b = 0.f;
     if (r < d && i < n0) {
       a = (float)W[(int64_t)r * ldw + i];                 // coalesced along i
-      b = (float)W[(int64_t)r * ldw + n0 + col[i]];       // gathered partner column
+      const int ci = col[i];
+      b = ci < 0 ? 0.f : (float)W[(int64_t)r * ldw + n0 + ci];  // gathered partner column (-1: unmatched)
     }
     t0[rr][tx] = a;
     t1[rr][tx] = b;
@@ -52,7 +54,8 @@ __global__ void refit_pairs_kernel(const double* __restrict__ W, int64_t ldw, co
   for (int ii = ty; ii < 32; ii += 8) {
     const int i = i0 + ii, r = r0 + tx;
     if (i < n0 && r < d) {
-      const float si = s0[i], sj = s1[col[i]];
+      const int ci = col[i];
+      const float si = s0[i], sj = ci < 0 ? 0.f : s1[ci];
       const float a = si / (si + sj), b = sj / (si + sj);
       out[(int64_t)i * d + r] = a * t0[tx][ii] + b * t1[tx][ii];
     }
