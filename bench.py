@@ -63,11 +63,16 @@ def make_level(m_local, n, fan_in, device, seed):
 
 def level_front(ops, lv, dist=None):
     """First half of a level: ground-metric Gram of this rank's rows (+ the all-reduce, left in flight)."""
-    G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32', split_bf16=lv.get('split_bf16', False))
     if dist is None:
+        G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32', split_bf16=lv.get('split_bf16', False))
         return G, na, nb, None, None
-    from neuron_interpolation_model_fusion_amd.parallel import pack_gram
-    buf = pack_gram(G, na, nb)  # one packed f64 all-reduce per level
+    # one packed f64 buffer [G | na | nb] per level: the Gram kernel's reduction writes straight into it and it goes
+    # into the single all-reduce as it is
+    from neuron_interpolation_model_fusion_amd.parallel import unpack_gram
+    n0, n1 = lv['act_k'].shape[1], lv['act_f'].shape[1]
+    buf = torch.empty(n0 * n1 + n0 + n1, dtype=torch.float64, device=lv['act_k'].device)
+    G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32', split_bf16=lv.get('split_bf16', False),
+                        out=unpack_gram(buf, n0, n1))
     # ordinary stream-ordered collective on the front stream: RCCL runs it on its own stream and the front
     # stream waits for it, so it overlaps with the back half of the previous level on the other stream
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)

@@ -42,7 +42,7 @@ def _ld(t):
 
 
 def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, trans_b=False, norms=True,
-        rows_sharded=False, split_bf16=False):
+        rows_sharded=False, split_bf16=False, out=None):
     """G = A^T B over the rows (f64, n0 x n1) and the squared column norms (f64).
 
     rows_sharded=True marks a contraction over the fusion samples: inside a
@@ -52,6 +52,8 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
     acc: 'f32' (exact-f32 MFMA per row block, f64 across blocks) or 'f64' (f64 MFMA).
     split_bf16=True (f32 inputs, acc 'f32', no transposes): the products run as six bf16 matrix instructions
     on the exact three-way bf16 split of every operand -- f32-level accuracy, different last bits.
+    out=(G, na, nb): contiguous f64 device tensors to write into (e.g. views of one packed buffer that goes
+    straight into an all-reduce) instead of fresh allocations.
     Returns (G, na, nb); na/nb are None when norms=False.
     """
     symmetric = B is None
@@ -73,9 +75,19 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
              (_lib.NIF_SYMMETRIC if symmetric else 0) | (_lib.NIF_TRANS_A if trans_a else 0) |
              (_lib.NIF_TRANS_B if trans_b else 0) | (_lib.NIF_XTY_SPLIT_BF16 if split_bf16 else 0))
     with torch.cuda.device(A.device):
-        G = torch.empty((n0, n1), dtype=torch.float64, device=A.device)
-        na = torch.empty(n0, dtype=torch.float64, device=A.device) if norms else None
-        nb = torch.empty(n1, dtype=torch.float64, device=A.device) if norms else None
+        if out is not None:
+            G, na, nb = out
+            ok = (G.dtype == torch.float64 and G.shape == (n0, n1) and G.is_contiguous() and G.device == A.device and
+                  all(t is None or (t.dtype == torch.float64 and t.is_contiguous() and t.device == A.device and
+                                    t.numel() == n) for t, n in ((na, n0), (nb, n1))))
+            if not ok or (norms and (na is None or nb is None)):
+                raise ValueError('xty: out must be contiguous float64 (n0 x n1, n0, n1) tensors on the operands\' device')
+            if not norms:
+                na = nb = None
+        else:
+            G = torch.empty((n0, n1), dtype=torch.float64, device=A.device)
+            na = torch.empty(n0, dtype=torch.float64, device=A.device) if norms else None
+            nb = torch.empty(n1, dtype=torch.float64, device=A.device) if norms else None
         nbytes = lib.nif_xty_workspace_bytes(m, n0, n1, accv, flags)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=A.device)
         check(lib.nif_xty(_ptr(A), _ld(A), _ptr(B), _ld(B), m, n0, n1, _DT[A.dtype], accv, flags,

@@ -610,3 +610,18 @@ def test_lap_scipy_order_rejects_invalid_costs_like_scipy(ops):
         linear_sum_assignment(nan.numpy())
     with pytest.raises(ValueError):
         ops.lap_solve(nan.cuda(), scipy_order=True)
+
+
+def test_xty_writes_into_caller_buffers(ops):
+    """out=: the reduction writes into views of one packed buffer (what the sharded level hands to the all-reduce)."""
+    from neuron_interpolation_model_fusion_amd.parallel import unpack_gram, pack_gram
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(500, 40, generator=g).cuda()
+    B = torch.randn(500, 24, generator=g).cuda()
+    G, na, nb = ops.xty(A, B)
+    buf = torch.full((40 * 24 + 40 + 24,), float('nan'), dtype=torch.float64, device='cuda')
+    G2, na2, nb2 = ops.xty(A, B, out=unpack_gram(buf, 40, 24))
+    assert G2.data_ptr() == buf.data_ptr()
+    assert torch.equal(buf, pack_gram(G, na, nb))
+    with pytest.raises(ValueError):
+        ops.xty(A, B, out=(G.float(), na, nb))
