@@ -38,18 +38,22 @@ def parse_args():
     p.add_argument('--use_kl_kd_on_head', action='store_true')
     p.add_argument('--kd_temperature', type=float, default=2.0)
     p.add_argument('--verbose', action='store_true')
+    p.add_argument('--head_weights_per_dataset_class', action='store_true',
+                   help='Not a reference flag. The reference computes the classifier-head shares with '
+                        'num_classes=args.num_models (run_alf.py:114), which only broadcasts against the logits when '
+                        'the number of models equals the number of classes; this flag counts the dataset classes instead.')
     c.add_data_args(p)
     return p.parse_args()
 
 
 def build_fusion_config(args, models, dataset, device, num_classes):
     num_levels = get_num_levels(models)
-    cls_head_weights = None
-    if args.use_weighted_loss:
-        # the reference passes num_classes=args.num_models here (run_alf.py:117), which only broadcasts against the
-        # logits when the two happen to be equal; the per-class shares need the number of classes
-        shares = get_classifier_head_weights(models, dataset, num_classes=num_classes)
-        cls_head_weights = torch.from_numpy(shares).float().to(device)
+    # run_alf.py:114-115 as written: the shares are always computed, with num_classes=args.num_models, kept in
+    # float64, and used only under --use_weighted_loss.  --head_weights_per_dataset_class (ours) swaps in the
+    # dataset's class count; nothing else changes.
+    head_classes = num_classes if args.head_weights_per_dataset_class else args.num_models
+    cls_head_weights = get_classifier_head_weights(models, dataset, num_classes=head_classes)
+    cls_head_weights = torch.from_numpy(cls_head_weights).to(device) if args.use_weighted_loss else None
 
     def expand(name, cast):
         vals = [cast(x.strip()) for x in getattr(args, name).split(',')]

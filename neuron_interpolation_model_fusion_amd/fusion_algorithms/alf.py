@@ -25,6 +25,7 @@ from tqdm import trange
 
 from .. import ops
 from ..models.base_model import BaseModel
+from ..parallel import SampleSharding, allgather_rows, broadcast_parameters
 from ..utils.fusion_utils import get_num_levels, normalize_activations_per_sample, compute_neuron_importance_scores
 from ..utils.model_utils import (
     is_conv_activation, is_transformer_activation, reset_parameters, soft_reset_parameters, disable_dropout)
@@ -182,8 +183,10 @@ class ALFusion:
         Kept for API compatibility (small inputs: the class-wise logit mean of the last level)."""
         assignment = torch.as_tensor(assignment, device=acts.device).long()
         w = torch.ones(acts.shape[0], device=acts.device) if weights is None else weights.to(acts.device).float()
-        sums = torch.zeros(output_size, acts.shape[1], device=acts.device).index_add_(0, assignment, acts * w[:, None])
-        tot = torch.zeros(output_size, device=acts.device).index_add_(0, assignment, w)
+        w = w.to(acts.dtype)  # float64 head weights promote the logits (run_alf.py:114-115): keep their precision
+        sums = torch.zeros(output_size, acts.shape[1], device=acts.device, dtype=acts.dtype).index_add_(
+            0, assignment, acts * w[:, None])
+        tot = torch.zeros(output_size, device=acts.device, dtype=acts.dtype).index_add_(0, assignment, w)
         live = tot > 0
         return sums[live] / tot[live][:, None]
 
@@ -443,6 +446,15 @@ class ALFusion:
         # gathers (the reference builds per-sample Dataset / DataLoader objects over the same tensors)
         level_X = level_X.to(self.device).float().contiguous()
         T = T.to(self.device).float().contiguous()
+        sharding = SampleSharding._active
+        if sharding is not None:
+            # The regression is not a row sum: it visits the samples in the loaders' order.  Its inputs and targets
+            # (rows = this rank's samples) are gathered in rank order, so every rank holds the rows of the
+            # un-sharded run and fits the level on all of them -- the replicated tail of the sharded path.  The
+            # fit draws from torch's CPU generator (split, shuffles, re-initialisation): ranks seeded alike walk
+            # the same trajectory, and the level is broadcast from rank 0 afterwards so that none can drift.
+            level_X = allgather_rows(level_X, sharding.group)
+            T = allgather_rows(T, sharding.group)
         train_idx, val_idx = self._split_indices(level_X.shape[0])
         val_order = val_idx.to(self.device)
         batch_size = fusion_config.train_batch_size
@@ -499,6 +511,8 @@ class ALFusion:
 
         if train_graph is not None and train_graph.graph is not None:
             optimizer.zero_grad(set_to_none=True)  # the gradients lived in the graph's private pool
+        if sharding is not None:
+            broadcast_parameters(network, 0, sharding.group)
         weights_after = nn.utils.parameters_to_vector(network.parameters()).detach().clone()
         weight_change = torch.norm(weights_after - weights_before).item()
         self.weight_change_per_level.append(weight_change)

@@ -4,6 +4,7 @@ The API is kept verbatim because it is the boundary of the hot path: the fusion
 algorithms only ever touch a model through the members defined here.
 """
 import contextlib
+import os
 from abc import ABC, abstractmethod
 from typing import NamedTuple
 
@@ -29,18 +30,20 @@ class LevelRepresentation(NamedTuple):
 
 # copy_model() builds a fresh instance and loads the weights into it (models/vgg.py:120-125 ...): the random
 # initialisation of that instance is thrown away, yet it is most of the host time of a small fusion (27 of 69 ms for two
-# 784-8192-10 MLPs).  The matching algorithms draw nothing from torch's generator afterwards, so they construct their
-# copies under this context; ALF, whose batch order follows that generator, does not.  Set
-# `twin_copy.replay_init_draws = True` to consume the generator exactly as the reference does everywhere.
+# 784-8192-10 MLPs).  The matching algorithms construct their copies under `twin_copy()`.  By DEFAULT that context does
+# nothing, so torch's generator is consumed exactly as the reference consumes it and whatever is seeded downstream in
+# the same process (an ALF run, fine-tuning, the next CLI loop iteration) stays draw-for-draw identical.  The fast mode
+# (`NIF_FAST_TWIN_COPY=1` in the environment, or `twin_copy.replay_init_draws = False`) skips the discarded
+# initialisation: same fused weights, different generator state afterwards.
 _RANDOM_INITS = ('kaiming_uniform_', 'kaiming_normal_', 'uniform_', 'normal_', 'xavier_uniform_', 'xavier_normal_',
                  'trunc_normal_')
 
 
 @contextlib.contextmanager
 def twin_copy():
-    """Context for copy_model() calls whose random initialisation is overwritten at once: the initialisers leave the
-    (uninitialised) storage alone and torch's generator is not advanced.  It swaps functions of torch.nn.init for
-    the duration of the block: not for use while another thread constructs modules."""
+    """Context for copy_model() calls whose random initialisation is overwritten at once.  In the fast mode the
+    initialisers leave the (uninitialised) storage alone and torch's generator is not advanced; it swaps functions of
+    torch.nn.init for the duration of the block, so it is not for use while another thread constructs modules."""
     if twin_copy.replay_init_draws:
         yield
         return
@@ -54,7 +57,7 @@ def twin_copy():
             setattr(nn.init, name, fn)
 
 
-twin_copy.replay_init_draws = False
+twin_copy.replay_init_draws = os.environ.get('NIF_FAST_TWIN_COPY', '0') != '1'
 
 
 class BaseModel(nn.Module, ABC):

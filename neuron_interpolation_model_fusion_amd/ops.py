@@ -94,7 +94,15 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
                           _ptr(G), n1, _ptr(na), _ptr(nb), _ptr(ws), nbytes, _stream()), 'nif_xty')
     if rows_sharded:
         from .parallel import SampleSharding
-        G, na, nb = SampleSharding.reduce(G, na, nb, symmetric=symmetric)
+        Gr, nar, nbr = SampleSharding.reduce(G, na, nb, symmetric=symmetric)
+        if out is not None and Gr is not G:  # the caller's buffers must hold what is returned: the reduced sums
+            G.copy_(Gr)
+            if na is not None:
+                na.copy_(nar)
+            if nb is not None:
+                nb.copy_(nbr)
+        else:
+            G, na, nb = Gr, nar, nbr
     return G, na, nb
 
 
@@ -270,9 +278,10 @@ def design_matrix(x, kernel_size=None, stride=1, padding=0, ones=True):
     OH, OW = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
     d = C * kh * kw + (1 if ones else 0)
     ld = (d + 3) // 4 * 4
-    out = torch.empty((B * OH * OW, ld), dtype=torch.float32, device=x.device)
-    check(lib.nif_im2row_f32(_ptr(x), B, C, H, W, kh, kw, sh, sw, ph, pw, 1 if ones else 0, _ptr(out), ld, _stream()),
-          'nif_im2row_f32')
+    with torch.cuda.device(x.device):
+        out = torch.empty((B * OH * OW, ld), dtype=torch.float32, device=x.device)
+        check(lib.nif_im2row_f32(_ptr(x), B, C, H, W, kh, kw, sh, sw, ph, pw, 1 if ones else 0, _ptr(out), ld,
+                                 _stream()), 'nif_im2row_f32')
     return out[:, :d]
 
 

@@ -94,6 +94,37 @@ def allreduce_gram(G, na=None, nb=None, group=None, symmetric=False):
     return unpack_gram(buf, n0, n1, na is not None, nb is not None)
 
 
+def allgather_rows(t, group=None):
+    """Concatenation over the ranks (in rank order) of every rank's rows of `t` -- the row shards of one
+    sample-indexed tensor put back together on every rank.  Shards may differ in length (shard_rows balances
+    them to within one row): they are padded to the longest for the collective.  A no-op outside a group."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    world = dist.get_world_size(group)
+    rows = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.empty_like(rows) for _ in range(world)]
+    dist.all_gather(counts, rows, group=group)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    mine = t.contiguous()
+    if mine.shape[0] < longest:
+        pad = torch.zeros((longest - mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        mine = torch.cat([mine, pad], dim=0)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Overwrite every parameter and buffer of `module` with rank `src`'s (after a replicated computation that
+    must not drift between ranks)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+
+
 class SampleSharding:
     """Context: inside it, ops.xty calls whose contraction axis is the sample axis reduce their
     outputs over `group` (the host classes mark those calls with rows_sharded=True).

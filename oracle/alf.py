@@ -109,3 +109,34 @@ def kmeans_v2(level_acts, k, sample_weight, normalize, init_with_2nd, num_runs=1
             tot[best[i]] += sample_weight[i]
         T, _, _ = match_T_to_X(level_X, T, tot)
     return unflatten_target(T, k, height, width, seqlen), best
+
+
+def last_level_grouping(models, X, num_classes, head_weights=None, use_kd=False, temperature=2.0):
+    """Class-wise target of the last level, alf.py:398-412: every model's logits, optionally scaled by its
+    per-class share (:404-405) and softened (:406-407), then the plain mean over the models of each class
+    column (the `_calculate_centroids` call of :411 has unit weights and the clusters {c, C + c, ...})."""
+    cols = []
+    with torch.no_grad():
+        for i, m in enumerate(models):
+            logits = m(X)
+            if head_weights is not None:
+                logits = logits * head_weights[i]
+            if use_kd:
+                logits = (logits / temperature).softmax(dim=1)
+            cols.append(logits)
+    stacked = torch.stack(cols, dim=0)          # [M, B, C]
+    T = stacked.sum(dim=0) / len(models)
+    assignment = torch.cat([torch.arange(num_classes) for _ in models])
+    return T, assignment
+
+
+def head_criterion(use_weighted_loss, head_weights, use_kd, cluster_weights):
+    """The loss `_get_criterion` (alf.py:424-454) selects for the LAST level, as a plain function of
+    (prediction, target): nn.MSELoss when the weighted loss is off or no head weights are given (:434-435,
+    tested first -- also under use_kd); KLDivLoss(batchmean) on the raw outputs under use_kd
+    (:438-439); else the importance-weighted squared error (:441-454)."""
+    if not use_weighted_loss or head_weights is None:
+        return lambda p, t: torch.mean((p - t) ** 2)
+    if use_kd:
+        return lambda p, t: torch.sum(torch.where(t > 0, t * (torch.log(t) - p), torch.zeros_like(p))) / p.shape[0]
+    return lambda p, t: torch.mean((p - t) ** 2 * cluster_weights)

@@ -24,6 +24,7 @@ What is recorded, per fixture (keys are flat strings inside one npz):
   kf{M}.assign{l}             KF best assignment per layer (M models), under np.random.seed(SEED)
   kf{M}.fused.<param>
   alf.T.{norm}{init2}, alf.assign.{norm}{init2}   ALFusion._k_means_v2 at level 0
+  (alf_kd.npz) head_w, grp.T.{hw}{kd}, kd{A,B,C,D}.fused.<param>   last-level grouping / criteria / KD pass (alf.py:398-454)
 """
 import contextlib
 import io
@@ -328,7 +329,67 @@ def fixture_mlp_real():
     return out
 
 
+def fixture_alf_kd():
+    """Last level of ALF (alf.py:398-454) and the head-only KD pass of run_alf.py:189-199: `_last_level_grouping`
+    with / without `cls_head_weights` and `use_kd_on_head`, and `fuse` with `skip_levels = range(L - 1)` under each
+    criterion branch of `_get_criterion` (KLDivLoss, head-weighted squared error, plain MSE on softened targets)."""
+    out = {}
+    models = []
+    for k in range(2):
+        torch.manual_seed(500 + k)
+        models.append(MLPNet(20, 32, 10, use_bias=True, use_activations=False).eval())
+    torch.manual_seed(7)
+    X = torch.randn(64, 1, 4, 5)
+    shares = torch.rand(2, 10, dtype=torch.float64) + 0.1
+    head_w = shares / shares.sum(dim=0, keepdim=True)   # what get_classifier_head_weights returns: float64 shares
+    out['X'] = X.numpy()
+    out['head_w'] = head_w.numpy()
+    for k, m in enumerate(models):
+        sd_to(out, f'sd{k}', m)
+    nlev = len(models[0].get_ordered_trainable_named_levels)
+
+    def config(**kw):
+        base = dict(X=X, y=None, optimizer_per_level=['sgd'] * nlev, lr_per_level=[5e-2] * nlev,
+                    weight_decay_per_level=[0.0] * nlev, epochs_per_level=[3] * nlev, verbose=False)
+        base.update(kw)
+        return ref_alf.ALFusionConfig(**base)
+
+    alf = ref_alf.ALFusion(models)
+    for hw in (0, 1):
+        for kd in (0, 1):
+            cfg = config(cls_head_weights=head_w if hw else None, use_kd_on_head=bool(kd), kd_temperature=2.0)
+            T, assign = alf._last_level_grouping(10, cfg)
+            out[f'grp.T.{hw}{kd}'] = T.numpy()
+            out[f'grp.assign.{hw}{kd}'] = assign.numpy().astype(np.int64)
+
+    variants = {
+        # run_alf.py --use_weighted_loss --run_last_layer_kd --use_kl_kd_on_head: KLDivLoss branch (alf.py:438-439)
+        'kdA': dict(use_weighted_loss=True, cls_head_weights=head_w, use_kd_on_head=True, kd_temperature=2.0),
+        # head weights without KD: importance-weighted squared error on the head (alf.py:441-454)
+        'kdB': dict(use_weighted_loss=True, cls_head_weights=head_w, use_kd_on_head=False),
+        # KD targets without the weighted loss: nn.MSELoss on the softened probabilities (alf.py:434-435, SURVEY D9)
+        'kdC': dict(use_weighted_loss=False, cls_head_weights=None, use_kd_on_head=True, kd_temperature=2.0),
+        # weighted loss requested but no head weights: still nn.MSELoss at the last level (alf.py:434)
+        'kdD': dict(use_weighted_loss=True, cls_head_weights=None, use_kd_on_head=True, kd_temperature=3.0),
+    }
+    for tag, kw in variants.items():
+        cfg = config(skip_levels=list(range(nlev - 1)), **kw)
+        copies = [m.copy_model() for m in models]
+        torch.manual_seed(SEED)
+        a = ref_alf.ALFusion(copies)
+        with contextlib.redirect_stderr(io.StringIO()):
+            fused = quiet(a.fuse, cfg)
+        sd_to(out, f'{tag}.fused', fused)
+        out[f'{tag}.weight_change'] = np.array(a.weight_change_per_level, dtype=np.float64)
+    meta(out)
+    np.savez_compressed(os.path.join(OUT, 'alf_kd.npz'), **out)
+    return out
+
+
+FIXTURES = dict(mlp_small=fixture_mlp_small, mlp_wide=fixture_mlp_wide, vgg_tiny=fixture_vgg_tiny,
+                vit_tiny=fixture_vit_tiny, mlp_real=fixture_mlp_real, alf_kd=fixture_alf_kd)
+
 if __name__ == '__main__':
-    for fx in (fixture_mlp_small, fixture_mlp_wide, fixture_vgg_tiny, fixture_vit_tiny, fixture_mlp_real):
+    for fx in [FIXTURES[n] for n in sys.argv[1:]] or list(FIXTURES.values()):
         o = fx()
         print(fx.__name__, len(o), 'arrays')

@@ -132,3 +132,76 @@ def test_c5_symmetric_gram_shard(ops):
     from neuron_interpolation_model_fusion_amd.parallel import pack_gram_upper, unpack_gram_upper
     G2, na2 = unpack_gram_upper(pack_gram_upper(G, na), N)
     assert torch.equal(G2, G) and torch.equal(na2, na)
+
+
+def test_c5_width_3072_shard_and_kmeans(ops):
+    """C5 at the wide (MLP-hidden) level: 8 models x 3072 units = N = 24 576, one rank's 25 000 rows, k = 3072.
+    Symmetric-Gram identities, the packed-triangle layout the sharded all-reduce sends for N > 2048, the KF
+    farthest-point initialisation against a sequential restatement, Lloyd monotonicity, targets = cluster means."""
+    m, N, k = 25000, 24576, 3072
+    g = torch.Generator(device='cuda').manual_seed(11)
+    base = torch.randn(m, k, device='cuda', generator=g)
+    A = torch.empty(m, N, device='cuda')
+    for j in range(8):  # eight noisy, permuted views of the same k units: clusters exist
+        perm = torch.randperm(k, device='cuda', generator=g)
+        A[:, j * k:(j + 1) * k] = base[:, perm] + 0.5 * torch.randn(m, k, device='cuda', generator=g)
+    del base
+    G, na, _ = ops.xty(A, None)
+    assert G.shape == (N, N)
+    for r0 in range(0, N, 4096):  # symmetry, block-wise (no second N x N f64 temporary)
+        assert torch.equal(G[r0:r0 + 4096, :], G[:, r0:r0 + 4096].T)
+    assert torch.allclose(G.diagonal(), na, rtol=2e-5)
+    x = torch.randn(N, device='cuda', dtype=torch.float64, generator=g)
+    quad = x @ (G @ x)
+    Ax = torch.zeros(m, device='cuda', dtype=torch.float64)
+    for c0 in range(0, N, 4096):
+        Ax += A[:, c0:c0 + 4096].double() @ x[c0:c0 + 4096]
+    ref = Ax.pow(2).sum()
+    assert abs(quad - ref) / ref < 1e-5
+    # the block upper triangle the sharded path all-reduces (parallel.allreduce_gram, taken for N > 2 * TRI_BLOCK)
+    from neuron_interpolation_model_fusion_amd import parallel
+    assert N > 2 * parallel.TRI_BLOCK
+    buf = parallel.pack_gram_upper(G, na)
+    assert buf.numel() < 0.53 * N * N
+    G2, na2 = parallel.unpack_gram_upper(buf, N)
+    for r0 in range(0, N, 4096):
+        assert torch.equal(G2[r0:r0 + 4096], G[r0:r0 + 4096])
+    assert torch.equal(na2, na)
+    del G2, buf
+    # KF farthest-point initialisation (hf_kf.py:424-441) at full size against the sequential definition
+    s = torch.ones(N, device='cuda')
+    km = ops.KMeans(G, na, s, k)
+    first = 17
+    picks, assign = km.farthest_init(first)
+    diag = G.diagonal()
+    p = first
+    mind = lab = None
+    ref_picks = [first]
+    for c in range(k):
+        d = (diag[p] - 2 * G[p] + na).clamp_min(0).sqrt()
+        if c == 0:
+            mind, lab = d.clone(), torch.zeros(N, dtype=torch.long, device='cuda')
+        else:
+            upd = d < mind
+            mind = torch.where(upd, d, mind)
+            lab = torch.where(upd, torch.full_like(lab, c), lab)
+        if c + 1 < k:
+            p = int(torch.argmax(mind))
+            ref_picks.append(p)
+    assert picks.cpu().tolist() == ref_picks
+    assert torch.equal(assign.long(), lab)
+    # Lloyd: the objective never increases; labels stay in range
+    costs = []
+    for _ in range(4):
+        assign, nearest, cost, kprime = km.lloyd_step(assign)
+        costs.append(float(cost))
+    assert all(b <= a * (1 + 1e-9) for a, b in zip(costs, costs[1:])), costs
+    labl = assign.long()
+    assert int(labl.min()) >= 0 and int(labl.max()) < k
+    T, kp = km.targets(A, assign)
+    present = torch.unique(labl)
+    assert int(kp) == present.numel()
+    for idx in (0, present.numel() // 2, present.numel() - 1):
+        members = (labl == present[idx]).nonzero().squeeze(1)
+        refc = A[:, members].double().mean(dim=1)
+        assert torch.allclose(T[:, idx].double(), refc, rtol=1e-5, atol=1e-6)

@@ -167,6 +167,32 @@ def test_alf_fuse_end_to_end_matches_reference_golden(dev):
     np.testing.assert_allclose(np.array(alf.weight_change_per_level), z['alf.weight_change'], rtol=1e-2)
 
 
+@pytest.mark.parametrize('tag', ['kdA', 'kdB', 'kdC', 'kdD'])
+def test_alf_head_only_kd_pass_matches_reference_golden(dev, tag):
+    """The head-only pass of run_alf.py:189-199 (`skip_levels = range(L - 1)`, fresh copy of model 0) under every
+    last-level branch of alf.py:398-454: kdA = head weights + softened targets + KLDivLoss, kdB = head weights with
+    the importance-weighted squared error, kdC / kdD = softened targets under nn.MSELoss (weighted loss off / no
+    head weights).  Goldens: tests/golden/alf_kd.npz, minted from the imported reference."""
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusion
+    z = load_npz('alf_kd')
+    models, X = build_models('mlp_kd', z, dev)
+    head_w = torch.from_numpy(z['head_w']).to(dev)
+    kw = {'kdA': dict(use_weighted_loss=True, cls_head_weights=head_w, use_kd_on_head=True, kd_temperature=2.0),
+          'kdB': dict(use_weighted_loss=True, cls_head_weights=head_w, use_kd_on_head=False),
+          'kdC': dict(use_weighted_loss=False, cls_head_weights=None, use_kd_on_head=True, kd_temperature=2.0),
+          'kdD': dict(use_weighted_loss=True, cls_head_weights=None, use_kd_on_head=True, kd_temperature=3.0)}[tag]
+    cfg = _alf_config(X, 2, optimizer_per_level=['sgd'] * 2, lr_per_level=[5e-2] * 2, epochs_per_level=[3, 3],
+                      skip_levels=[0], **kw)
+    copies = [m.copy_model() for m in models]
+    torch.manual_seed(int(z['meta.seed'][0]))
+    alf = ALFusion(copies)
+    fused = alf.fuse(cfg)
+    assert_state_close(fused, fused_state(z, tag), rtol=1e-3)
+    np.testing.assert_allclose(np.array(alf.weight_change_per_level), z[f'{tag}.weight_change'], rtol=1e-2)
+    # the hidden level was skipped: it is still model 0's
+    assert torch.equal(fused.state_dict()['level1.1.weight'].cpu(), torch.from_numpy(z['sd0.level1.1.weight']))
+
+
 def test_alf_kmeans_vit_with_skip_alignment_matches_reference_golden(dev):
     from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusion
     z = load_npz('vit_tiny')
@@ -317,3 +343,42 @@ def test_otfusion_of_models_with_different_widths_matches_oracle(dev):
         fused = OTFusion(models[:-1], models[-1]).fuse_models(strategy)
         ref = o_otf.otf_fuse(cpu_models[:-1], cpu_models[-1], Xc, mode=mode)
         assert_state_close(fused, dict(ref.state_dict()), rtol=1e-3)
+
+
+@pytest.mark.parametrize('algo', ['gr', 'hf', 'kf', 'otf'])
+def test_torch_generator_state_after_fuse_equals_the_oracles(dev, algo):
+    """The reference's copy_model() calls (git_rebasin.py:139,230; hf_kf.py:543,568; otfusion.py:209,359) draw a
+    discarded random initialisation from torch's generator; the product consumes it identically by default, so
+    anything seeded downstream in the same process sees the same stream."""
+    import contextlib, io
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import GitRebasin, LSFusion, OTFusion
+    from oracle import git_rebasin as o_gr, hf_kf as o_hf, otfusion as o_otf
+    z = load_npz('mlp_small')
+    models, X = build_models('mlp_small', z, dev)
+    cpu_models, Xc = build_models('mlp_small', z, 'cpu')
+    strategy = {'mode': 'acts', 'acts': {'activations_dataset': X, 'activation_labels': None,
+                                         'neuron_importance_method': 'uniform', 'normalize_activations': False}}
+    torch.manual_seed(77)
+    np.random.seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        if algo == 'gr':
+            o_gr.gr_fuse(cpu_models[0], cpu_models[1], Xc)
+        elif algo == 'hf':
+            o_hf.ls_fuse(cpu_models[:2], Xc, 'hungarian')
+        elif algo == 'kf':
+            o_hf.ls_fuse(cpu_models[:2], Xc, 'k_means')
+        else:
+            o_otf.otf_fuse(cpu_models[:1], cpu_models[1], Xc, mode='acts')
+    expected = torch.get_rng_state()
+    torch.manual_seed(77)
+    np.random.seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        if algo == 'gr':
+            GitRebasin(models[0], models[1]).fuse(X, None, 'uniform')
+        elif algo == 'hf':
+            LSFusion(models[:2]).fuse(X, None, fusion_method='hungarian', neuron_importance_method='uniform')
+        elif algo == 'kf':
+            LSFusion(models[:2]).fuse(X, None, fusion_method='k_means', neuron_importance_method='uniform')
+        else:
+            OTFusion(models[:1], models[1]).fuse_models(strategy)
+    assert torch.equal(torch.get_rng_state(), expected)

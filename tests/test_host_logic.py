@@ -102,29 +102,68 @@ def test_forward_level_walks_the_same_outputs_as_forward_until_level():
             assert torch.equal(acts, model(X))
 
 
-def test_twin_copy_skips_the_discarded_random_init():
-    """copy_model() under twin_copy(): same weights, torch's generator untouched; with replay_init_draws the
-    generator advances exactly as a plain copy_model() (the reference's behaviour, models/mlp.py:46-53) does."""
+def test_twin_copy_default_replays_the_init_draws_and_fast_mode_skips_them():
+    """copy_model() under twin_copy(): by default torch's generator advances exactly as a plain copy_model() (the
+    reference's behaviour, models/mlp.py:46-53); in the opt-in fast mode the generator is untouched.  Same weights
+    either way."""
     import torch
     from neuron_interpolation_model_fusion_amd.models import MLPNet
     from neuron_interpolation_model_fusion_amd.models.base_model import twin_copy
+    assert twin_copy.replay_init_draws is True  # parity mode is the default (NIF_FAST_TWIN_COPY unset)
     torch.manual_seed(5)
     m = MLPNet(20, 16, 4, use_bias=True, use_activations=False)
     state = torch.get_rng_state()
-    with twin_copy():
-        c = m.copy_model()
-    assert torch.equal(torch.get_rng_state(), state)
-    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), c.state_dict().values()))
-    assert torch.nn.init.kaiming_uniform_.__module__ == 'torch.nn.init'  # restored
     plain = m.copy_model()
     after_plain = torch.get_rng_state()
     assert not torch.equal(after_plain, state)
     torch.set_rng_state(state)
-    twin_copy.replay_init_draws = True
+    with twin_copy():
+        c = m.copy_model()
+    assert torch.equal(torch.get_rng_state(), after_plain)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+    torch.set_rng_state(state)
+    twin_copy.replay_init_draws = False
     try:
         with twin_copy():
-            m.copy_model()
-        assert torch.equal(torch.get_rng_state(), after_plain)
+            fast = m.copy_model()
+        assert torch.equal(torch.get_rng_state(), state)
+        assert torch.nn.init.kaiming_uniform_.__module__ == 'torch.nn.init'  # restored
     finally:
-        twin_copy.replay_init_draws = False
-    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), plain.state_dict().values()))
+        twin_copy.replay_init_draws = True
+    assert all(torch.equal(a, b) for a, b in zip(fast.state_dict().values(), plain.state_dict().values()))
+
+
+def test_alf_last_level_grouping_and_criterion_branches_match_reference_golden():
+    """alf.py:398-454 on the host class itself (plain torch, runs on the CPU): the class-wise logit targets with /
+    without head weights and softening against tests/golden/alf_kd.npz, and the criterion each branch selects."""
+    import numpy as np
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import ALFusionConfig
+    from tests.helpers import load_npz, build_models
+    z = load_npz('alf_kd')
+    models, X = build_models('mlp_kd', z)
+    head_w = torch.from_numpy(z['head_w'])
+    alf = ALFusion(models)
+    alf.ni_scores = [{1: torch.ones(10)} for _ in models]
+
+    def cfg(**kw):
+        return ALFusionConfig(X=X, y=None, optimizer_per_level=['sgd'] * 2, lr_per_level=[0.05] * 2,
+                              weight_decay_per_level=[0.0] * 2, epochs_per_level=[1] * 2, verbose=False, **kw)
+    for hw in (0, 1):
+        for kd in (0, 1):
+            T, assign = alf._last_level_grouping(10, cfg(cls_head_weights=head_w if hw else None,
+                                                          use_kd_on_head=bool(kd), kd_temperature=2.0))
+            assert (assign.numpy() == z[f'grp.assign.{hw}{kd}']).all()
+            np.testing.assert_allclose(T.numpy(), z[f'grp.T.{hw}{kd}'], rtol=1e-6, atol=1e-7)
+    assign = torch.cat([torch.arange(10), torch.arange(10)])
+    kl = alf._get_criterion(1, 10, assign, cfg(use_weighted_loss=True, cls_head_weights=head_w, use_kd_on_head=True), True)
+    assert isinstance(kl, torch.nn.KLDivLoss) and kl.reduction == 'batchmean'
+    for kw in (dict(use_weighted_loss=False, cls_head_weights=head_w, use_kd_on_head=True),
+               dict(use_weighted_loss=True, cls_head_weights=None, use_kd_on_head=True)):
+        assert alf._get_criterion(1, 10, assign, cfg(**kw), True).__name__ == 'mse_loss'
+    wl = alf._get_criterion(1, 10, assign, cfg(use_weighted_loss=True, cls_head_weights=head_w), True)
+    assert wl.__name__ == 'weighted_loss'
+    # a hidden level never takes the head branches
+    assert alf.ni_scores[0].setdefault(0, torch.ones(32)) is not None and alf.ni_scores[1].setdefault(0, torch.ones(32)) is not None
+    hidden = alf._get_criterion(0, 32, torch.cat([torch.arange(32)] * 2),
+                                cfg(use_weighted_loss=True, cls_head_weights=head_w, use_kd_on_head=True), False)
+    assert hidden.__name__ == 'weighted_loss'

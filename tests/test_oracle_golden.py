@@ -122,3 +122,29 @@ def test_alf_kmeans_oracle_vit_with_skip_alignment():
             tag = f'{int(norm)}{int(init2)}'
             assert (assign.numpy() == z[f'alf.assign.{tag}']).all(), tag
             np.testing.assert_allclose(T.numpy(), z[f'alf.T.{tag}'], rtol=1e-5, atol=1e-6)
+
+
+def test_alf_last_level_grouping_oracle():
+    """alf.py:398-412 with / without cls_head_weights and use_kd_on_head (goldens: tests/golden/alf_kd.npz)."""
+    z = load_npz('alf_kd')
+    models, X = build_models('mlp_kd', z)
+    head_w = torch.from_numpy(z['head_w'])
+    for hw in (0, 1):
+        for kd in (0, 1):
+            T, assign = o_alf.last_level_grouping(models, X, 10, head_w if hw else None, bool(kd), 2.0)
+            assert (assign.numpy() == z[f'grp.assign.{hw}{kd}']).all()
+            ref = z[f'grp.T.{hw}{kd}']
+            assert T.numpy().dtype == ref.dtype  # float64 head weights promote the targets, as in the reference
+            np.testing.assert_allclose(T.numpy(), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_alf_head_criterion_oracle_matches_torch_modules():
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(8, 10, generator=g)
+    t = torch.softmax(torch.randn(8, 10, generator=g), dim=1)
+    w = torch.rand(10, generator=g)
+    hw = torch.ones(2, 10)
+    assert torch.allclose(o_alf.head_criterion(False, hw, True, w)(p, t), torch.nn.MSELoss()(p, t))
+    assert torch.allclose(o_alf.head_criterion(True, None, True, w)(p, t), torch.nn.MSELoss()(p, t))
+    assert torch.allclose(o_alf.head_criterion(True, hw, True, w)(p, t), torch.nn.KLDivLoss(reduction='batchmean')(p, t))
+    assert torch.allclose(o_alf.head_criterion(True, hw, False, w)(p, t), ((p - t) ** 2 * w).mean())

@@ -98,3 +98,34 @@ def test_symmetric_gram_reduces_only_the_block_upper_triangle():
         out = mgr.dict()
         mp.spawn(_worker_sym, args=(2, _free_port(), out), nprocs=2, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def _worker_gather(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from neuron_interpolation_model_fusion_amd import parallel
+        full = torch.arange(7 * 3 * 2, dtype=torch.float32).view(7, 3, 2)   # 7 rows over 2 ranks: shards of 3 and 4
+        lo, hi = parallel.shard_rows(7)
+        got = parallel.allgather_rows(full[lo:hi].clone())
+        ok = torch.equal(got, full)
+        lin = torch.nn.Linear(3, 2)
+        with torch.no_grad():
+            lin.weight.fill_(float(rank + 1))
+        parallel.broadcast_parameters(lin, 0)
+        ok = ok and bool((lin.weight == 1.0).all())
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_rows_restores_ragged_row_shards_and_broadcast_aligns_parameters():
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_gather, args=(2, _free_port(), out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
+    # outside a process group both are the identity
+    from neuron_interpolation_model_fusion_amd import parallel
+    t = torch.randn(5, 2)
+    assert parallel.allgather_rows(t) is t
