@@ -152,6 +152,19 @@ size_t nif_lap_workspace_bytes(int n);
 int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
                       double* u, double* v, void* ws, size_t ws_bytes, void* stream);
 
+/* The same solve for callers that cannot allocate device memory or hand over a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference.  The
+ * scratch the kernels need (column-minimum partials, claim words, stand-ins for optional outputs) lives in a
+ * static device array inside libnif.so -- NIF_LAP_STATIC_BYTES per GPU the library runs on, held until the
+ * process ends; its address on the current device is looked up once per device.  The call itself allocates and
+ * frees nothing and records no timing events.  n > NIF_LAP_STATIC_MAX_N returns NIF_ERR_UNSUPPORTED (with a line
+ * on stderr).  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race; calls ordered on one stream are safe.  Arguments and results are those of nif_lap_solve_f32. */
+#define NIF_LAP_STATIC_MAX_N 2048
+#define NIF_LAP_STATIC_BYTES (640 * 1024)
+int nif_lap_solve_f32_static(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
+                             double* u, double* v, void* stream);
+
 /* Uniqueness certificate (no counterpart in the reference: it is what lets a call site that must reproduce
  * scipy.optimize.linear_sum_assignment -- hf_kf.py:251, git_rebasin.py:112, alf.py:138,383 -- take the fast solver's
  * answer): count[0] (device) = number of edges outside the matching whose reduced cost C[i][j] - u[i] - v[j] is

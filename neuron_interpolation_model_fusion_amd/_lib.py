@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libnif.so')
 NIF_F32, NIF_F64 = 0, 1
 NIF_RELU_A, NIF_RELU_B, NIF_SYMMETRIC, NIF_TRANS_A, NIF_TRANS_B, NIF_XTY_SPLIT_BF16 = 1, 2, 4, 8, 16, 32
 NIF_LAP_MAX_N = 8192
+NIF_LAP_STATIC_MAX_N = 2048
 NIF_LAP_SCIPY_ORDER = 1
 NIF_LAP_INIT_ONLY = 2
 NIF_LAP_RESUME = 4
@@ -42,6 +43,7 @@ SIGNATURES = {
     'nif_cost_hf': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'nif_lap_workspace_bytes': (_sz, [_i32]),
     'nif_lap_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nif_lap_solve_f32_static': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'nif_kmeans_workspace_bytes': (_sz, [_i32, _i32]),
     'nif_kmeans_farthest_init': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'nif_kmeans_assign_to_neurons': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp]),

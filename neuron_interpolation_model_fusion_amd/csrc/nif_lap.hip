@@ -13,6 +13,7 @@
 // the f32 cost matrix; it equals scipy's wherever that optimum is unique.
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <mutex>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -406,14 +407,76 @@ extern "C" size_t nif_lap_workspace_bytes(int n) {
   return nif::lap_ws(n).total;
 }
 
+namespace nif {
+// Both entry points below run this: `ws` is the caller's workspace (nif_lap_solve_f32) or the per-device address of
+// the library's static scratch array (nif_lap_solve_f32_static).  `timed` = record the NIF_PROF_LAP span (creates
+// HIP events, which allocates: the static entry point never asks for it).
+static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col, double* u,
+                        double* v, void* ws, hipStream_t st, bool timed);
+}  // namespace nif
+
 extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
                                  double* u, double* v, void* ws, size_t ws_bytes, void* stream) {
   using namespace nif;
   if (!C || !col4row || n <= 0 || ldc < n) return NIF_ERR_INVALID_ARG;
   if (n > NIF_LAP_MAX_N) return NIF_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < lap_ws(n).total) return NIF_ERR_WORKSPACE;
+  return lap_solve_on(C, ldc, n, flags, col4row, row4col, u, v, ws, reinterpret_cast<hipStream_t>(stream), true);
+}
+
+// ---- the entry point that allocates nothing -------------------------------------------------------------------
+// Scratch of the assignment kernels (column-minimum partials, claim / best-column words, stand-ins for optional
+// outputs) for n <= NIF_LAP_STATIC_MAX_N, in the code object's own memory: every GPU the library runs on holds one
+// copy until the process ends.  In host code the array's NAME is only a handle; its device address on the current
+// GPU comes from hipGetSymbolAddress, once per device, and is what the kernels receive.
+namespace nif {
+constexpr size_t LAP_STATIC_BYTES = NIF_LAP_STATIC_BYTES;  // >= lap_ws(NIF_LAP_STATIC_MAX_N).total, checked at run time
+static __device__ __align__(256) unsigned char scratch[LAP_STATIC_BYTES];
+
+constexpr int LAP_MAX_DEVICES = 64;
+static std::mutex scratch_mu;
+static void* scratch_ptr[LAP_MAX_DEVICES];  // per device: each GPU has its own copy at its own address
+
+static int lap_static_scratch(void** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LAP_MAX_DEVICES) return NIF_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lock(scratch_mu);
+  if (!scratch_ptr[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // with `dev` current
+    if (e != hipSuccess || !p) {
+      fprintf(stderr, "[libnif] hipGetSymbolAddress(scratch) on device %d: %s\n", dev, hipGetErrorString(e));
+      return NIF_ERR_NO_DEVICE;
+    }
+    scratch_ptr[dev] = p;
+  }
+  *out = scratch_ptr[dev];
+  return NIF_OK;
+}
+}  // namespace nif
+
+extern "C" int nif_lap_solve_f32_static(const float* C, int64_t ldc, int n, int flags, int32_t* col4row,
+                                        int32_t* row4col, double* u, double* v, void* stream) {
+  using namespace nif;
+  if (!C || !col4row || n <= 0 || ldc < n) return NIF_ERR_INVALID_ARG;
+  if (n > NIF_LAP_STATIC_MAX_N) {
+    fprintf(stderr, "[libnif] nif_lap_solve_f32_static: n = %d exceeds NIF_LAP_STATIC_MAX_N = %d (the static scratch "
+                    "is sized for that; use nif_lap_solve_f32 with a caller workspace)\n", n, NIF_LAP_STATIC_MAX_N);
+    return NIF_ERR_UNSUPPORTED;
+  }
+  if (lap_ws(n).total > LAP_STATIC_BYTES) return NIF_ERR_WORKSPACE;  // cannot happen for n <= the maximum
+  void* ws = nullptr;
+  const int rc = lap_static_scratch(&ws);
+  if (rc != NIF_OK) return rc;
+  // every word the kernels read from the scratch is written by an earlier kernel of the same call, so nothing
+  // left by the previous call (possibly for a larger n) has to be cleared
+  return lap_solve_on(C, ldc, n, flags, col4row, row4col, u, v, ws, reinterpret_cast<hipStream_t>(stream), false);
+}
+
+namespace nif {
+static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col, double* u,
+                        double* v, void* ws, hipStream_t st, bool timed) {
   const LapWs w = lap_ws(n);
-  if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   clear_err();
   unsigned char* b = reinterpret_cast<unsigned char*>(ws);
   float* part = reinterpret_cast<float*>(b + w.off_part);
@@ -454,7 +517,7 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   int threads = ((n + cpt - 1) / cpt + 63) / 64 * 64;
   if (threads > 1024) return NIF_ERR_UNSUPPORTED;
   const size_t lds = (size_t)((3 * n + 3) & ~3) * sizeof(int) + LAP_MBOX_TOTAL * sizeof(int);
-  prof_begin(NIF_PROF_LAP, st);
+  if (timed) prof_begin(NIF_PROF_LAP, st);
 #define NIF_LAP_GO(CPT)                                                                       \
   do {                                                                                        \
     if (scipy_order) launch_augment<CPT, true>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, 0); \
@@ -467,9 +530,10 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
     default: NIF_LAP_GO(8); break;
   }
 #undef NIF_LAP_GO
-  prof_end(NIF_PROF_LAP, st);
+  if (timed) prof_end(NIF_PROF_LAP, st);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
+}  // namespace nif
 
 extern "C" int nif_lap_count_tight_f32(const float* C, int64_t ldc, int n, const int32_t* col4row, const double* u,
                                        const double* v, double tol_rel, int32_t* count, void* stream) {
