@@ -286,6 +286,20 @@ int nif_wmse_backward(const float* pred, const float* truth, const float* w, con
 int nif_im2row_f32(const float* x, int64_t batch, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
                    int add_ones, float* out, int64_t ldo, void* stream);
 
+/* ---- symmetric eigendecomposition with a relative cutoff: the factor step of the LS refit ----------------------
+ * torch.linalg.pinv (hf_kf.py:213,377) drops the singular values <= rtol * sigma_max of the design matrix; on the
+ * normal equations G = X^T X (or X X^T) that keeps the eigenpairs with lambda > rtol^2 * lambda_max.  G: n x n f64,
+ * symmetric (ldg), not modified.  Returns K = number of eigenvalues > cutoff_rel * lambda_max in *kept_host (HOST
+ * int), their values ascending in lam[0 .. K) and the orthonormal eigenvectors as the COLUMNS of V[:, 0 .. K) (V: n
+ * rows, ldv >= n doubles per row).  Householder tridiagonalisation (one fused update + matrix-vector pass per column),
+ * Sturm-count multisection, inverse iteration with in-cluster re-orthogonalisation, blocked back-transformation --
+ * hand-written kernels, no vendor solver.  The call blocks the host ONCE on `stream` (to learn K, which sizes the
+ * eigenvector launches).  n <= NIF_EIGH_MAX_N. */
+#define NIF_EIGH_MAX_N 6144
+size_t nif_eigh_kept_workspace_bytes(int n);
+int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cutoff_rel, double* lam, double* V, int64_t ldv,
+                      int32_t* kept_host, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

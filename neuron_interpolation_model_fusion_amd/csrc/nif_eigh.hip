@@ -1,0 +1,692 @@
+// nif_eigh.hip -- symmetric eigendecomposition with a relative cutoff, hand-written for gfx950: the factor step of
+// the least-squares refit (torch.linalg.pinv at hf_kf.py:213,377 drops singular values <= rtol * sigma_max, so the
+// normal equations need the eigenpairs above rtol^2 * lambda_max, not a Cholesky factor).
+//
+//   1. Householder tridiagonalisation, one launch per column: the rank-2 update of step j-1 and the matrix-vector
+//      product of step j are fused into ONE pass over the trailing matrix (every element is read once and written
+//      once per column), row blocks spread over the whole chip; the O(n) vector work of a step (reflector, w) is
+//      recomputed by every workgroup from L2-resident vectors, so a step needs no grid-wide synchronisation beyond
+//      the launch boundary.
+//   2. Eigenvalues of the tridiagonal matrix by Sturm-count multisection: one wavefront per eigenvalue, its 64 lanes
+//      evaluate the count at 64 points of the bracket per pass (9 passes instead of 53 bisection steps).
+//   3. Eigenvectors of the KEPT eigenvalues by inverse iteration (LU with partial pivoting of T - lambda I, one lane
+//      per eigenvector, lanes in lock step over the rows, factors stored [row][vector] for coalescing), distinct
+//      pseudo-random starts, modified Gram-Schmidt inside groups of eigenvalues closer than 1e-9 |T|.
+//   4. Back-transformation by blocks of 64 reflectors without forming T: (I - V T V^T) Z = Z - V Y with
+//      (diag(1/tau) + striu(V^T V)) Y = V^T Z; the two products with the long contraction run on the f64 matrix
+//      cores (nif_xty), the triangular solve and the rank-64 update are small dedicated kernels.
+//
+// Everything is f64.  The entry point synchronises the stream ONCE (after step 2) to learn how many eigenpairs are
+// kept: that count is an output and sizes the launches of steps 3-4.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/nif.h"
+#include "nif_common.h"
+
+namespace nif {
+
+constexpr int TRD_T = 512;      // threads of a tridiagonalisation workgroup (8 waves)
+constexpr int TRD_ROWS = 4;     // rows a wave carries through the trailing pass together
+constexpr int EIG_NB = 64;      // reflectors per back-transformation block
+
+// deterministic block-wide sum (same value in every workgroup that runs the same code on the same data)
+template <int T>
+__device__ __forceinline__ double block_sum(double x, double* red /* T/64 + 1 doubles of LDS */) {
+  x = wave_sum_f64(x);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();  // red may still be read from a previous call
+  if (lane == 0) red[wv] = x;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w) s += red[w];
+  return s;
+}
+
+struct TrdArgs {
+  double* A;       // n x ld, symmetric, both triangles kept current; ld even, pad column zero
+  int64_t ld;
+  int n;
+  int j;           // column being eliminated
+  double* vbuf;    // 2 x ld: reflector of step j at parity j & 1 (rows j+1 .. n-1, v[j+1] = 1)
+  double* ybuf;    // 2 x ld: y_j = (updated trailing matrix) v_j
+  double* d;       // diagonal of T
+  double* e;       // sub-diagonal of T
+  double* tau;     // reflector scales
+};
+
+// One column of the reduction.  LDS: sv1 = v_{j-1}, sw = w_{j-1}, svj = v_j, each ld doubles, indexed by column.
+__global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n = a.n, j = a.j, tid = threadIdx.x;
+  const int64_t ld = a.ld;
+  double* sv1 = reinterpret_cast<double*>(smem_raw);
+  double* sw = sv1 + ld;
+  double* svj = sw + ld;
+  double* red = svj + ld;
+  const double* vprev = a.vbuf + (size_t)((j + 1) & 1) * ld;  // parity of j - 1
+  const double* yprev = a.ybuf + (size_t)((j + 1) & 1) * ld;
+  double* vcur = a.vbuf + (size_t)(j & 1) * ld;
+  double* ycur = a.ybuf + (size_t)(j & 1) * ld;
+  const int c0 = (j + 1) & ~1;               // first column of the 16-byte aligned trailing pass (j or j + 1)
+  const int cend = (n + 1) & ~1;             // one pad column when n is odd
+  const bool pending = j > 0;
+
+  // (a) w_{j-1} = p + alpha v with p = tau y, alpha = -tau/2 (p . v): rows j .. n-1 (v_{j-1}[j] = 1)
+  for (int c = c0 + tid; c < cend; c += TRD_T) { sv1[c] = 0.0; sw[c] = 0.0; svj[c] = 0.0; }
+  if (tid == 0) { sv1[j] = 0.0; sw[j] = 0.0; svj[j] = 0.0; }
+  __syncthreads();
+  if (pending) {
+    const double tau1 = a.tau[j - 1];
+    double part = 0.0;
+    for (int r = j + tid; r < n; r += TRD_T) {
+      const double v = vprev[r], p = tau1 * yprev[r];
+      sv1[r] = v;
+      sw[r] = p;
+      part += p * v;
+    }
+    const double dot = block_sum<TRD_T>(part, red);
+    const double alpha = -0.5 * tau1 * dot;
+    for (int r = j + tid; r < n; r += TRD_T) sw[r] += alpha * sv1[r];
+    __syncthreads();
+  }
+  // (b) row j of the updated matrix (= its column j): a_c = A[j][c] - v[j] w[c] - w[j] v[c]
+  const double vj_ = pending ? sv1[j] : 0.0, wj_ = pending ? sw[j] : 0.0;
+  double part2 = 0.0;
+  for (int c = j + tid; c < n; c += TRD_T) {
+    const double x = a.A[(size_t)j * ld + c] - vj_ * sw[c] - wj_ * sv1[c];
+    svj[c] = x;
+    if (c >= j + 2) part2 += x * x;
+  }
+  const double xnorm2 = block_sum<TRD_T>(part2, red);
+  const double djj = svj[j], alpha0 = svj[j + 1];
+  double tau, beta, scale;
+  if (xnorm2 == 0.0) {
+    tau = 0.0; beta = alpha0; scale = 0.0;
+  } else {
+    beta = -copysign(sqrt(alpha0 * alpha0 + xnorm2), alpha0);
+    tau = (beta - alpha0) / beta;
+    scale = 1.0 / (alpha0 - beta);
+  }
+  __syncthreads();
+  for (int c = j + 2 + tid; c < n; c += TRD_T) svj[c] *= scale;
+  if (tid == 0) {
+    svj[j + 1] = 1.0;
+    svj[j] = 0.0;          // column j is finished: masked out of the trailing pass when c0 == j
+    sv1[j] = 0.0;
+    sw[j] = 0.0;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (tid == 0) { a.d[j] = djj; a.e[j] = beta; a.tau[j] = tau; }
+    for (int r = j + 1 + tid; r < n; r += TRD_T) vcur[r] = svj[r];
+  }
+
+  // (c) trailing pass over rows j+1 .. n-1: apply the pending rank-2 update, store, and accumulate y = A v_j
+  const int lane = tid & 63, wv = tid >> 6;
+  const int nrows = n - (j + 1);
+  const int ngroups = (nrows + TRD_ROWS - 1) / TRD_ROWS;
+  const int gw = blockIdx.x * (TRD_T / 64) + wv, nw = gridDim.x * (TRD_T / 64);
+  for (int g = gw; g < ngroups; g += nw) {
+    const int r0 = j + 1 + g * TRD_ROWS;
+    double vr[TRD_ROWS], wr[TRD_ROWS], acc[TRD_ROWS];
+    double* row[TRD_ROWS];
+#pragma unroll
+    for (int q = 0; q < TRD_ROWS; ++q) {
+      const int r = r0 + q < n ? r0 + q : n - 1;  // clamped duplicates are discarded below
+      vr[q] = sv1[r];
+      wr[q] = sw[r];
+      acc[q] = 0.0;
+      row[q] = a.A + (size_t)r * ld;
+    }
+    for (int c = c0 + 2 * lane; c < cend; c += 128) {
+      const double2 w2 = *reinterpret_cast<const double2*>(sw + c);
+      const double2 v2 = *reinterpret_cast<const double2*>(sv1 + c);
+      const double2 u2 = *reinterpret_cast<const double2*>(svj + c);
+      double2 x[TRD_ROWS];
+#pragma unroll
+      for (int q = 0; q < TRD_ROWS; ++q) x[q] = *reinterpret_cast<const double2*>(row[q] + c);
+#pragma unroll
+      for (int q = 0; q < TRD_ROWS; ++q) {
+        x[q].x -= vr[q] * w2.x + wr[q] * v2.x;
+        x[q].y -= vr[q] * w2.y + wr[q] * v2.y;
+        acc[q] += x[q].x * u2.x + x[q].y * u2.y;
+        if (pending && r0 + q < n) *reinterpret_cast<double2*>(row[q] + c) = x[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TRD_ROWS; ++q) {
+      const double s = wave_sum_f64(acc[q]);
+      const int r = r0 + q;
+      if (lane == 0 && r < n) {
+        ycur[r] = s;
+        if (r >= j + 2) a.A[(size_t)r * ld + j] = svj[r];  // reflector j, stored below the sub-diagonal of column j
+      }
+    }
+  }
+}
+
+// After the last step (j = n - 3): apply the pending update to the trailing 2 x 2 block.  n >= 3.
+__global__ void trd_finish_kernel(TrdArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = a.n, jl = n - 3;
+  const int64_t ld = a.ld;
+  const double* v = a.vbuf + (size_t)(jl & 1) * ld;
+  const double* y = a.ybuf + (size_t)(jl & 1) * ld;
+  const double tau1 = a.tau[jl];
+  const int r0 = n - 2, r1 = n - 1;
+  const double p0 = tau1 * y[r0], p1 = tau1 * y[r1];
+  const double alpha = -0.5 * tau1 * (p0 * v[r0] + p1 * v[r1]);
+  const double w0 = p0 + alpha * v[r0], w1 = p1 + alpha * v[r1];
+  a.d[r0] = a.A[(size_t)r0 * ld + r0] - 2.0 * v[r0] * w0;
+  a.e[r0] = a.A[(size_t)r1 * ld + r0] - v[r1] * w0 - w1 * v[r0];
+  a.d[r1] = a.A[(size_t)r1 * ld + r1] - 2.0 * v[r1] * w1;
+  a.tau[r0] = 0.0;
+}
+
+// n <= 2: nothing to reduce
+__global__ void trd_small_kernel(TrdArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  a.d[0] = a.A[0];
+  if (a.n == 2) {
+    a.e[0] = a.A[a.ld];
+    a.d[1] = a.A[a.ld + 1];
+    a.tau[0] = 0.0;
+  }
+}
+
+// ---- eigenvalues of the tridiagonal matrix ---------------------------------------------------------------------
+// params[0] = tnorm (max row sum of |T|), [1] = pivmin, [2] = lower Gershgorin bound, [3] = upper bound
+__global__ void tri_bounds_kernel(const double* __restrict__ d, const double* __restrict__ e, int n, double* params) {
+  const int tid = threadIdx.x;
+  double tn = 0.0, lo = INFINITY, hi = -INFINITY, e2m = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double el = i > 0 ? fabs(e[i - 1]) : 0.0, er = i + 1 < n ? fabs(e[i]) : 0.0;
+    tn = fmax(tn, fabs(d[i]) + el + er);
+    lo = fmin(lo, d[i] - el - er);
+    hi = fmax(hi, d[i] + el + er);
+    e2m = fmax(e2m, er * er);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    tn = fmax(tn, shfl_xor_f64(tn, o));
+    lo = fmin(lo, shfl_xor_f64(lo, o));
+    hi = fmax(hi, shfl_xor_f64(hi, o));
+    e2m = fmax(e2m, shfl_xor_f64(e2m, o));
+  }
+  __shared__ double r_tn[4], r_lo[4], r_hi[4], r_e2[4];
+  if ((tid & 63) == 0) { r_tn[tid >> 6] = tn; r_lo[tid >> 6] = lo; r_hi[tid >> 6] = hi; r_e2[tid >> 6] = e2m; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) {
+      tn = fmax(tn, r_tn[w]); lo = fmin(lo, r_lo[w]); hi = fmax(hi, r_hi[w]); e2m = fmax(e2m, r_e2[w]);
+    }
+    if (!(tn > 0.0)) tn = DBL_MIN;
+    const double pivmin = DBL_MIN * fmax(1.0, e2m);
+    const double slack = 2.0 * tn * DBL_EPSILON * n + 2.0 * pivmin;
+    params[0] = tn;
+    params[1] = pivmin;
+    params[2] = lo - slack;
+    params[3] = hi + slack;
+  }
+}
+
+constexpr int BIS_T = 512;  // 8 eigenvalues per workgroup share one LDS copy of T
+
+// lam[k] = k-th smallest eigenvalue.  One wave per eigenvalue; pass = 64 Sturm counts inside the bracket.
+__global__ __launch_bounds__(BIS_T) void tri_eigenvalues_kernel(const double* __restrict__ d, const double* __restrict__ e,
+                                                                int n, const double* __restrict__ params,
+                                                                double* __restrict__ lam) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* sd = reinterpret_cast<double*>(smem_raw);
+  double* se2 = sd + n;
+  for (int i = threadIdx.x; i < n; i += BIS_T) {
+    sd[i] = d[i];
+    const double x = i + 1 < n ? e[i] : 0.0;
+    se2[i] = x * x;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * (BIS_T / 64) + (threadIdx.x >> 6);
+  if (k >= n) return;
+  const double tnorm = params[0], pivmin = params[1];
+  double lo = params[2], hi = params[3];
+  const double tol = DBL_EPSILON * tnorm;
+  for (int pass = 0; pass < 14 && hi - lo > tol; ++pass) {
+    const double x = lo + (hi - lo) * ((double)(lane + 1) / 65.0);
+    double q = sd[0] - x;
+    if (fabs(q) < pivmin) q = -pivmin;
+    int cnt = q < 0.0;
+    for (int i = 1; i < n; ++i) {
+      q = sd[i] - x - se2[i - 1] / q;
+      if (fabs(q) < pivmin) q = -pivmin;
+      cnt += q < 0.0;
+    }
+    // lambda_k < x  <=>  at least k + 1 eigenvalues lie below x
+    const unsigned long long below = __ballot(cnt > k);
+    const int first = below ? __ffsll((long long)below) - 1 : 64;
+    const double xl = lo, xh = hi, w = xh - xl;
+    if (first < 64) hi = xl + w * ((double)(first + 1) / 65.0);
+    if (first > 0) lo = xl + w * ((double)first / 65.0);
+  }
+  if (lane == 0) lam[k] = 0.5 * (lo + hi);
+}
+
+// kept eigenvalues = those above cutoff_rel * lambda_max; shifts for the inverse iteration: the rule
+// s_j = max(lam_j, s_{j-1} + pert), pert = 10 eps |T| (coincident eigenvalues get distinct factorizations), which
+// unrolls to s_j = max_t (lam_{j-t} + t pert): every thread scans back over the eigenvalues within n * pert of its own
+// (a handful at most unless the spectrum is numerically multiple).  kept[0] = K.
+__global__ void tri_select_kernel(const double* __restrict__ lam, int n, double cutoff_rel, const double* params,
+                                  double* __restrict__ shifts, int* __restrict__ kept) {
+  const double lmax = lam[n - 1];
+  const double thr = cutoff_rel * lmax;
+  int lo = 0, hi = n;  // first index with lam > thr (lam ascending)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (lam[mid] > thr) hi = mid; else lo = mid + 1;
+  }
+  const int K = n - lo;
+  if (blockIdx.x == 0 && threadIdx.x == 0) kept[0] = K;
+  const double pert = 10.0 * DBL_EPSILON * params[0];
+  const double reach = (double)n * pert;
+  for (int jj = blockIdx.x * blockDim.x + threadIdx.x; jj < K; jj += gridDim.x * blockDim.x) {
+    const double mine = lam[lo + jj];
+    double best = mine;
+    for (int t = 1; t <= jj; ++t) {
+      const double other = lam[lo + jj - t];
+      if (mine - other > reach) break;
+      const double cand = other + (double)t * pert;
+      if (cand > best) best = cand;
+    }
+    shifts[jj] = best;
+  }
+}
+
+__device__ __forceinline__ double hash_unit(unsigned i, unsigned jj) {
+  unsigned long long x = (unsigned long long)i * 0x9E3779B97F4A7C15ull ^ ((unsigned long long)jj * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull);
+  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+  return (double)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+struct InvitArgs {
+  const double* d; const double* e; int n;
+  const double* shifts; int K; const double* params;
+  double* inv; double* du; double* du2; double* dl; unsigned char* pv;  // LU factors, [row][K]
+  double* Z; int64_t ldz;                                                 // n x K eigenvectors (columns)
+  int iters;
+};
+
+// One lane per kept eigenvector; the lanes of a wave walk the rows together (uniform loads of d, e; coalesced
+// stores of the factors).
+__global__ __launch_bounds__(64) void tri_invit_kernel(InvitArgs a) {
+  const int jj = blockIdx.x * 64 + threadIdx.x;
+  if (jj >= a.K) return;
+  const int n = a.n;
+  const int64_t K = a.K;
+  const double lam = a.shifts[jj];
+  const double tiny = DBL_EPSILON * a.params[0];
+  auto guard = [tiny](double p) { return fabs(p) < tiny ? (p < 0.0 ? -tiny : tiny) : p; };
+  // factor T - lam I = P L U
+  double ca = a.d[0] - lam, cb = n > 1 ? a.e[0] : 0.0;
+  for (int i = 0; i + 1 < n; ++i) {
+    const double c = a.e[i], nd = a.d[i + 1] - lam, ne = i + 2 < n ? a.e[i + 1] : 0.0;
+    const bool swap = fabs(c) > fabs(ca);
+    double piv, u1, u2, l, na_, nb_;
+    if (!swap) {
+      piv = guard(ca);
+      const double r = 1.0 / piv;
+      l = c * r;
+      u1 = cb; u2 = 0.0;
+      na_ = nd - l * cb; nb_ = ne;
+      a.inv[i * K + jj] = r;
+    } else {
+      piv = c;
+      const double r = 1.0 / piv;
+      l = ca * r;
+      u1 = nd; u2 = ne;
+      na_ = cb - l * nd; nb_ = -l * ne;
+      a.inv[i * K + jj] = r;
+    }
+    a.du[i * K + jj] = u1;
+    a.du2[i * K + jj] = u2;
+    a.dl[i * K + jj] = l;
+    a.pv[i * K + jj] = swap ? 1 : 0;
+    ca = na_; cb = nb_;
+  }
+  a.inv[(int64_t)(n - 1) * K + jj] = 1.0 / guard(ca);
+  // start vector
+  double* z = a.Z + jj;
+  const int64_t ldz = a.ldz;
+  for (int i = 0; i < n; ++i) z[i * ldz] = hash_unit((unsigned)i, (unsigned)jj);
+  double nrm2 = 0.0;
+  for (int it = 0; it < a.iters; ++it) {
+    // forward: y = L^-1 P x
+    double cur = z[0];
+    for (int i = 0; i + 1 < n; ++i) {
+      const double nxt = z[(i + 1) * ldz];
+      const bool swap = a.pv[i * K + jj] != 0;
+      const double top = swap ? nxt : cur, bot = swap ? cur : nxt;
+      z[i * ldz] = top;
+      cur = bot - a.dl[i * K + jj] * top;
+    }
+    // backward: U x = y
+    double x1 = cur * a.inv[(int64_t)(n - 1) * K + jj], x2 = 0.0;
+    z[(int64_t)(n - 1) * ldz] = x1;
+    nrm2 = x1 * x1;
+    for (int i = n - 2; i >= 0; --i) {
+      const double xi = (z[i * ldz] - a.du[i * K + jj] * x1 - a.du2[i * K + jj] * x2) * a.inv[i * K + jj];
+      z[i * ldz] = xi;
+      nrm2 += xi * xi;
+      x2 = x1; x1 = xi;
+    }
+    if (it + 1 < a.iters) {  // keep the iterate in range: three unscaled solves can reach 1e48, more would overflow
+      const double s = 1.0 / sqrt(nrm2);
+      for (int i = 0; i < n; ++i) z[i * ldz] *= s;
+    }
+  }
+  const double s = 1.0 / sqrt(nrm2);
+  for (int i = 0; i < n; ++i) z[i * ldz] *= s;
+}
+
+// Modified Gram-Schmidt (two passes) inside every maximal run of kept eigenvalues whose neighbours are closer than
+// ortol_rel * |T|: one wave per run, started by the run's first member; other waves leave at once.
+__global__ __launch_bounds__(64) void tri_mgs_kernel(const double* __restrict__ lam_kept, int K, int n,
+                                                     const double* __restrict__ params, double ortol_rel, double* Z,
+                                                     int64_t ldz) {
+  const int j0 = blockIdx.x, lane = threadIdx.x;
+  if (j0 >= K) return;
+  const double ortol = ortol_rel * params[0];
+  if (j0 > 0 && lam_kept[j0] - lam_kept[j0 - 1] <= ortol) return;    // not the first of its run
+  int j1 = j0;
+  while (j1 + 1 < K && lam_kept[j1 + 1] - lam_kept[j1] <= ortol) ++j1;
+  if (j1 == j0) return;
+  for (int aidx = j0 + 1; aidx <= j1; ++aidx) {
+    for (int rep = 0; rep < 2; ++rep) {
+      for (int b = j0; b < aidx; ++b) {
+        double dot = 0.0;
+        for (int i = lane; i < n; i += 64) dot += Z[i * ldz + b] * Z[i * ldz + aidx];
+        dot = wave_sum_f64(dot);
+        for (int i = lane; i < n; i += 64) Z[i * ldz + aidx] -= dot * Z[i * ldz + b];
+      }
+    }
+    double nn = 0.0;
+    for (int i = lane; i < n; i += 64) nn += Z[i * ldz + aidx] * Z[i * ldz + aidx];
+    nn = wave_sum_f64(nn);
+    const double s = 1.0 / sqrt(nn);
+    for (int i = lane; i < n; i += 64) Z[i * ldz + aidx] *= s;
+  }
+}
+
+// ---- back-transformation Z <- H_0 H_1 ... H_{n-3} Z -------------------------------------------------------------
+// Vb[(r - (j0 + 1))][l] = reflector j0 + l at row r, rows j0+1 .. n-1 (nr rows), nb columns (zero beyond nbk)
+__global__ void bt_extract_kernel(const double* __restrict__ A, int64_t ld, int n, int j0, int nbk, double* __restrict__ Vb) {
+  const int l = threadIdx.x & (EIG_NB - 1);
+  const int rr = blockIdx.x * (256 / EIG_NB) + (threadIdx.x / EIG_NB);
+  const int nr = n - (j0 + 1);
+  if (rr >= nr) return;
+  const int r = j0 + 1 + rr, j = j0 + l;
+  double v = 0.0;
+  if (l < nbk) {
+    if (r == j + 1) v = 1.0;
+    else if (r >= j + 2) v = A[(size_t)r * ld + j];
+  }
+  Vb[(size_t)rr * EIG_NB + l] = v;
+}
+
+// Y = T M with T^-1 = diag(1/tau) + striu(S): back substitution, one thread per column of M (nbk x K, ld ldm),
+// in place; the 64-column slice of M a workgroup owns is staged in LDS.  tau = 0 (identity reflector) gives a
+// zero row.
+__global__ __launch_bounds__(64) void bt_trsolve_kernel(const double* __restrict__ S, int64_t lds_,
+                                                        const double* __restrict__ tau, int nbk, double* __restrict__ M,
+                                                        int64_t ldm, int K) {
+  __shared__ double sS[EIG_NB * EIG_NB];
+  __shared__ double sY[EIG_NB][64 + 1];
+  __shared__ double st[EIG_NB];
+  const int tid = threadIdx.x;
+  for (int q = tid; q < nbk * nbk; q += 64) sS[(q / nbk) * EIG_NB + (q % nbk)] = S[(size_t)(q / nbk) * lds_ + (q % nbk)];
+  for (int q = tid; q < nbk; q += 64) st[q] = tau[q];
+  const int c = blockIdx.x * 64 + tid;
+  for (int i = 0; i < nbk; ++i) sY[i][tid] = c < K ? M[(size_t)i * ldm + c] : 0.0;
+  __syncthreads();
+  for (int i = nbk - 1; i >= 0; --i) {
+    double s = sY[i][tid];
+    for (int l = i + 1; l < nbk; ++l) s -= sS[i * EIG_NB + l] * sY[l][tid];
+    sY[i][tid] = st[i] * s;
+  }
+  if (c < K)
+    for (int i = 0; i < nbk; ++i) M[(size_t)i * ldm + c] = sY[i][tid];
+}
+
+// Z[j0+1+rr][c] -= sum_l Vb[rr][l] Y[l][c]: 64 x 64 tiles, 256 threads, 4 x 4 per thread, l in two halves of 32
+__global__ __launch_bounds__(256) void bt_update_kernel(const double* __restrict__ Vb, const double* __restrict__ Y,
+                                                        int64_t ldy, int nr, int nbk, int K, double* __restrict__ Zs,
+                                                        int64_t ldz) {
+  constexpr int LH = 32;
+  __shared__ double sV[64][LH + 1];
+  __shared__ double sY[LH][64 + 2];
+  const int r0 = blockIdx.y * 64, cb = blockIdx.x * 64, tid = threadIdx.x;
+  const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) acc[i][k2] = 0.0;
+  for (int l0 = 0; l0 < nbk; l0 += LH) {
+    __syncthreads();
+    for (int q = tid; q < 64 * LH; q += 256) {
+      const int rr = q / LH, l = l0 + q % LH;
+      sV[rr][q % LH] = (r0 + rr < nr && l < nbk) ? Vb[(size_t)(r0 + rr) * EIG_NB + l] : 0.0;
+    }
+    for (int q = tid; q < LH * 64; q += 256) {
+      const int l = l0 + q / 64, cc = q % 64;
+      sY[q / 64][cc] = (cb + cc < K && l < nbk) ? Y[(size_t)l * ldy + cb + cc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int l = 0; l < LH; ++l) {
+      double v[4], y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = sV[tr + i][l];
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) y[k2] = sY[l][tc + k2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) acc[i][k2] += v[i] * y[k2];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + tr + i;
+    if (r >= nr) continue;
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      const int c = cb + tc + k2;
+      if (c < K) Zs[(size_t)r * ldz + c] -= acc[i][k2];
+    }
+  }
+}
+
+// copy a symmetric matrix into the padded working layout (ld even, pad column zero)
+__global__ void eigh_copy_in_kernel(const double* __restrict__ G, int64_t ldg, int n, double* __restrict__ A, int64_t ld) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= ld) return;
+  A[(size_t)r * ld + c] = c < n ? G[(size_t)r * ldg + c] : 0.0;
+}
+
+__global__ void eigh_copy_lam_kernel(const double* __restrict__ lam, int n, int K, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K) out[i] = lam[n - K + i];
+}
+
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct EighWs {
+  size_t off_A, off_vbuf, off_ybuf, off_d, off_e, off_tau, off_lam, off_shift, off_params, off_kept;
+  size_t off_fac, off_pv, off_Vb, off_S, off_M, off_xty, total;
+  int64_t ld, ldz;
+  size_t xty_bytes;
+};
+
+static EighWs eigh_ws(int n) {
+  EighWs w;
+  w.ld = (n + 1) & ~(int64_t)1;
+  w.ldz = (n + 3) & ~(int64_t)3;
+  size_t o = 0;
+  auto take = [&o](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
+  w.off_A = take((size_t)n * w.ld * 8);
+  w.off_vbuf = take(2 * (size_t)w.ld * 8);
+  w.off_ybuf = take(2 * (size_t)w.ld * 8);
+  w.off_d = take((size_t)n * 8);
+  w.off_e = take((size_t)n * 8);
+  w.off_tau = take((size_t)n * 8);
+  w.off_lam = take((size_t)n * 8);
+  w.off_shift = take((size_t)n * 8);
+  w.off_params = take(8 * 8);
+  w.off_kept = take(64);
+  w.off_fac = take(4 * (size_t)n * n * 8);   // inv, du, du2, dl for up to n kept vectors
+  w.off_pv = take((size_t)n * n);
+  w.off_Vb = take((size_t)n * EIG_NB * 8);
+  w.off_S = take((size_t)EIG_NB * EIG_NB * 8);
+  w.off_M = take((size_t)EIG_NB * w.ldz * 8);
+  // nif_xty workspaces of the two products of a block (contraction over up to n rows)
+  size_t x1 = nif_xty_workspace_bytes(n, EIG_NB, EIG_NB, NIF_F64, NIF_SYMMETRIC);
+  size_t x2 = nif_xty_workspace_bytes(n, EIG_NB, n, NIF_F64, 0);
+  for (int nr = 64; nr < n; nr *= 2) {  // the split plan depends on the row count: size for the largest need
+    const size_t y1 = nif_xty_workspace_bytes(nr, EIG_NB, EIG_NB, NIF_F64, NIF_SYMMETRIC);
+    const size_t y2 = nif_xty_workspace_bytes(nr, EIG_NB, n, NIF_F64, 0);
+    if (y1 > x1) x1 = y1;
+    if (y2 > x2) x2 = y2;
+  }
+  w.xty_bytes = x1 > x2 ? x1 : x2;
+  w.off_xty = take(w.xty_bytes + 4096);
+  w.total = o;
+  return w;
+}
+
+}  // namespace nif
+
+extern "C" size_t nif_eigh_kept_workspace_bytes(int n) {
+  if (n <= 0 || n > NIF_EIGH_MAX_N) return 0;
+  return nif::eigh_ws(n).total;
+}
+
+extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cutoff_rel, double* lam, double* V,
+                                 int64_t ldv, int32_t* kept_host, void* ws, size_t ws_bytes, void* stream) {
+  using namespace nif;
+  if (!G || !lam || !V || !kept_host || n <= 0 || ldg < n || !(cutoff_rel >= 0.0)) return NIF_ERR_INVALID_ARG;
+  if (n > NIF_EIGH_MAX_N) return NIF_ERR_UNSUPPORTED;
+  const EighWs w = eigh_ws(n);
+  if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
+  if (ldv < n) return NIF_ERR_INVALID_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  clear_err();
+  unsigned char* b = reinterpret_cast<unsigned char*>(ws);
+  TrdArgs t;
+  t.A = reinterpret_cast<double*>(b + w.off_A);
+  t.ld = w.ld;
+  t.n = n;
+  t.j = 0;
+  t.vbuf = reinterpret_cast<double*>(b + w.off_vbuf);
+  t.ybuf = reinterpret_cast<double*>(b + w.off_ybuf);
+  t.d = reinterpret_cast<double*>(b + w.off_d);
+  t.e = reinterpret_cast<double*>(b + w.off_e);
+  t.tau = reinterpret_cast<double*>(b + w.off_tau);
+  double* lam_all = reinterpret_cast<double*>(b + w.off_lam);
+  double* shifts = reinterpret_cast<double*>(b + w.off_shift);
+  double* params = reinterpret_cast<double*>(b + w.off_params);
+  int* kept_dev = reinterpret_cast<int*>(b + w.off_kept);
+
+  // 1. tridiagonalisation
+  hipLaunchKernelGGL(eigh_copy_in_kernel, dim3((unsigned)((w.ld + 255) / 256), n), dim3(256), 0, st, G, ldg, n, t.A, w.ld);
+  if (n <= 2) {
+    hipLaunchKernelGGL(trd_small_kernel, dim3(1), dim3(64), 0, st, t);
+  } else {
+    const size_t lds = (3 * (size_t)w.ld + 16) * sizeof(double);
+    if (lds > 160 * 1024) return NIF_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)trd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    for (int j = 0; j + 2 < n; ++j) {
+      t.j = j;
+      const int nrows = n - (j + 1);
+      const int groups = (nrows + TRD_ROWS - 1) / TRD_ROWS;
+      int blocks = (groups + (TRD_T / 64) - 1) / (TRD_T / 64);   // one group of rows per wave when they all fit
+      if (blocks > 256) blocks = 256;
+      if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL(trd_step_kernel, dim3(blocks), dim3(TRD_T), lds, st, t);
+    }
+    hipLaunchKernelGGL(trd_finish_kernel, dim3(1), dim3(64), 0, st, t);
+  }
+  if (!launch_ok()) return NIF_ERR_LAUNCH;
+
+  // 2. eigenvalues, cutoff, shifts
+  hipLaunchKernelGGL(tri_bounds_kernel, dim3(1), dim3(256), 0, st, t.d, t.e, n, params);
+  {
+    const size_t lds = 2 * (size_t)n * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)tri_eigenvalues_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(tri_eigenvalues_kernel, dim3((n + BIS_T / 64 - 1) / (BIS_T / 64)), dim3(BIS_T), lds, st, t.d, t.e, n,
+                       params, lam_all);
+  }
+  hipLaunchKernelGGL(tri_select_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lam_all, n, cutoff_rel, params, shifts, kept_dev);
+  if (!launch_ok()) return NIF_ERR_LAUNCH;
+  int K = 0;
+  if (hipMemcpyAsync(&K, kept_dev, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return NIF_ERR_LAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return NIF_ERR_LAUNCH;
+  *kept_host = K;
+  if (K <= 0 || K > n) return K == 0 ? NIF_OK : NIF_ERR_LAUNCH;
+  hipLaunchKernelGGL(eigh_copy_lam_kernel, dim3((K + 255) / 256), dim3(256), 0, st, lam_all, n, K, lam);
+
+  // 3. eigenvectors of T (columns of V, n x K, ld ldv)
+  InvitArgs ia;
+  ia.d = t.d; ia.e = t.e; ia.n = n; ia.shifts = shifts; ia.K = K; ia.params = params;
+  double* fac = reinterpret_cast<double*>(b + w.off_fac);
+  ia.inv = fac;
+  ia.du = fac + (size_t)n * K;
+  ia.du2 = fac + 2 * (size_t)n * K;
+  ia.dl = fac + 3 * (size_t)n * K;
+  ia.pv = b + w.off_pv;
+  ia.Z = V;
+  ia.ldz = ldv;
+  ia.iters = 3;
+  hipLaunchKernelGGL(tri_invit_kernel, dim3((K + 63) / 64), dim3(64), 0, st, ia);
+  hipLaunchKernelGGL(tri_mgs_kernel, dim3(K), dim3(64), 0, st, lam, K, n, params, 1e-9, V, ldv);
+  if (!launch_ok()) return NIF_ERR_LAUNCH;
+
+  // 4. back-transformation, last block of reflectors first
+  if (n > 2) {
+    double* Vb = reinterpret_cast<double*>(b + w.off_Vb);
+    double* S = reinterpret_cast<double*>(b + w.off_S);
+    double* M = reinterpret_cast<double*>(b + w.off_M);
+    void* xws = b + w.off_xty;
+    const int nref = n - 2;
+    const int nblk = (nref + EIG_NB - 1) / EIG_NB;
+    for (int bi = nblk - 1; bi >= 0; --bi) {
+      const int j0 = bi * EIG_NB;
+      const int nbk = nref - j0 < EIG_NB ? nref - j0 : EIG_NB;
+      const int nr = n - (j0 + 1);
+      hipLaunchKernelGGL(bt_extract_kernel, dim3((nr + 3) / 4), dim3(256), 0, st, t.A, w.ld, n, j0, nbk, Vb);
+      int rc = nif_xty(Vb, EIG_NB, Vb, EIG_NB, nr, nbk, nbk, NIF_F64, NIF_F64, NIF_SYMMETRIC, S, EIG_NB, nullptr, nullptr,
+                       xws, w.xty_bytes, stream);
+      if (rc != NIF_OK) return rc;
+      double* Zs = V + (size_t)(j0 + 1) * ldv;
+      rc = nif_xty(Vb, EIG_NB, Zs, ldv, nr, nbk, K, NIF_F64, NIF_F64, 0, M, w.ldz, nullptr, nullptr, xws, w.xty_bytes,
+                   stream);
+      if (rc != NIF_OK) return rc;
+      hipLaunchKernelGGL(bt_trsolve_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, (int64_t)EIG_NB, t.tau + j0, nbk, M,
+                         w.ldz, K);
+      hipLaunchKernelGGL(bt_update_kernel, dim3((K + 63) / 64, (nr + 63) / 64), dim3(256), 0, st, Vb, M, w.ldz, nr, nbk, K,
+                         Zs, ldv);
+    }
+  }
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+}

@@ -285,6 +285,30 @@ def design_matrix(x, kernel_size=None, stride=1, padding=0, ones=True):
     return out[:, :d]
 
 
+def eigh_kept(G, cutoff_rel):
+    """Eigenpairs of the symmetric f64 matrix G above ``cutoff_rel * lambda_max`` (see nif_eigh_kept_f64): returns
+    (lam, V) with lam ascending (K,) and the orthonormal eigenvectors in the columns of V (n x K, a view of an
+    n x n buffer).  Hand-written tridiagonalisation / multisection / inverse iteration / back-transformation kernels;
+    the call blocks the host once (K is data-dependent)."""
+    _need_gpu(G)
+    if G.dim() != 2 or G.shape[0] != G.shape[1] or G.dtype != torch.float64:
+        raise TypeError('eigh_kept needs a square float64 matrix')
+    n = G.shape[0]
+    if n > _lib.NIF_EIGH_MAX_N:
+        raise _lib.NifError(f'eigh_kept: n={n} exceeds NIF_EIGH_MAX_N={_lib.NIF_EIGH_MAX_N}')
+    G = _mat(G, 'G')
+    with torch.cuda.device(G.device):
+        lam = torch.empty(n, dtype=torch.float64, device=G.device)
+        V = torch.empty((n, n), dtype=torch.float64, device=G.device)
+        nbytes = lib.nif_eigh_kept_workspace_bytes(n)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=G.device)
+        kept = ctypes.c_int32(0)
+        check(lib.nif_eigh_kept_f64(_ptr(G), _ld(G), n, float(cutoff_rel), _ptr(lam), _ptr(V), n, ctypes.byref(kept),
+                                    _ptr(ws), nbytes, _stream()), 'nif_eigh_kept_f64')
+    K = kept.value
+    return lam[:K], V[:, :K]
+
+
 def ls_solve(X, A, normalize=False):
     """Minimum-norm least squares W = pinv(X) @ A with torch.linalg.pinv's cutoff for f32 inputs
     (singular values <= max(m, d) * eps_f32 * sigma_max are dropped), from normal equations:
@@ -292,8 +316,8 @@ def ls_solve(X, A, normalize=False):
       m >= d:  G = X^T X, R = X^T A (f64 MFMA);  G = V L V^T;  W = V L_kept^-1 V^T R
       m <  d:  K = X X^T;  K = U L U^T;  W = X^T (U L_kept^-1 U^T A)          (dual form)
 
-    The Gram build and every dense product run on nif_xty; the symmetric eigendecomposition is
-    torch.linalg.eigh on the device for now (interim library call -- see DESIGN.md).
+    The Gram build and every dense product run on nif_xty; the symmetric eigendecomposition of the normal matrix is
+    nif_eigh_kept_f64 (hand-written kernels: no vendor solver on the path).
     normalize=True scales A's columns to unit norm first (fusion_utils.py:38-40).
     Returns dict(W (d x N f64), R = X^T A (d x N f64), na = squared column norms of A (N f64), rank).
     """
@@ -322,27 +346,33 @@ def ls_solve(X, A, normalize=False):
         if int(live.sum().item()) < d:
             idx = live.nonzero().squeeze(1)
             G = G.index_select(0, idx).index_select(1, idx)
-        lam, V = torch.linalg.eigh(G)
-        keep = lam > (rtol * rtol) * lam[-1]
-        inv_lam = torch.where(keep, 1.0 / lam, torch.zeros_like(lam))
-        Z, _, _ = xty(V, R if idx is None else R.index_select(0, idx), acc='f64', norms=False)   # V^T R
-        Z = Z * inv_lam[:, None]
-        W, _, _ = xty(V, Z, acc='f64', trans_a=True, norms=False)   # V Z
+        rank = 0
+        if G.shape[0] > 0:
+            lam, V = eigh_kept(G, rtol * rtol)   # only the eigenpairs pinv keeps
+            rank = lam.shape[0]
+        if rank > 0:
+            Z, _, _ = xty(V, R if idx is None else R.index_select(0, idx), acc='f64', norms=False)   # V^T R
+            Z = Z / lam[:, None]
+            W, _, _ = xty(V, Z, acc='f64', trans_a=True, norms=False)   # V Z
+        else:  # X = 0: pinv(X) = 0
+            W = torch.zeros((G.shape[0], R.shape[1]), dtype=torch.float64, device=X.device)
         if idx is not None:
             W = torch.zeros((d, W.shape[1]), dtype=W.dtype, device=W.device).index_copy_(0, idx, W)
     else:
         K, _, _ = xty(X, None, acc='f64', trans_a=True, norms=False)  # X X^T
-        lam, U = torch.linalg.eigh(K)
-        keep = lam > (rtol * rtol) * lam[-1]
-        inv_lam = torch.where(keep, 1.0 / lam, torch.zeros_like(lam))
-        A64 = A.double()
-        if normalize:
-            A64 = A64 * inv[None, :]
-        Z, _, _ = xty(U, A64, acc='f64', norms=False)        # U^T A
-        Z = Z * inv_lam[:, None]
-        Y, _, _ = xty(U, Z, acc='f64', trans_a=True, norms=False)   # U Z  (m x N)
-        W, _, _ = xty(X.double(), Y, acc='f64', norms=False)        # X^T Y
-    return dict(W=W, R=R, na=na, rank=int(keep.sum().item()))
+        lam, U = eigh_kept(K, rtol * rtol)
+        rank = lam.shape[0]
+        if rank > 0:
+            A64 = A.double()
+            if normalize:
+                A64 = A64 * inv[None, :]
+            Z, _, _ = xty(U, A64, acc='f64', norms=False)        # U^T A
+            Z = Z / lam[:, None]
+            Y, _, _ = xty(U, Z, acc='f64', trans_a=True, norms=False)   # U Z  (m x N)
+            W, _, _ = xty(X.double(), Y, acc='f64', norms=False)        # X^T Y
+        else:
+            W = torch.zeros((d, A.shape[1]), dtype=torch.float64, device=X.device)
+    return dict(W=W, R=R, na=na, rank=rank)
 
 
 def refit_pairs(W, col, s0, s1, n0):

@@ -58,6 +58,21 @@ def test_run_otf(savedir):
 
 
 def test_run_alf(savedir):
-    _run('run_alf.py', savedir, '--epochs_per_level', '2', '--use_weighted_loss', '--normalize_acts_for_kmeans',
-         '--run_last_layer_kd', '--lr_per_level', '0.001,0.0005')
+    # 2 models, 10 classes: with the reference's own head-weight call (num_classes=args.num_models, run_alf.py:114)
+    # --use_weighted_loss cannot broadcast the (2,) shares against the (B, 10) logits; --head_weights_per_dataset_class
+    # (ours) counts the dataset's classes
+    _run('run_alf.py', savedir, '--epochs_per_level', '2', '--use_weighted_loss', '--head_weights_per_dataset_class',
+         '--normalize_acts_for_kmeans', '--run_last_layer_kd', '--use_kl_kd_on_head', '--lr_per_level', '0.001,0.0005')
     _check_saved(savedir, ['alf-2-uniform.pt', 'alf-2-deeplift.pt', 'alf-2-logit-kd.pt'])
+
+
+def test_run_alf_default_flags_behave_like_the_reference(savedir):
+    """Same flags, same behaviour: without --use_weighted_loss the shares are computed and dropped (run_alf.py:114-115)
+    and the run succeeds; with it, the reference's shape error at alf.py:405 comes back unchanged."""
+    _run('run_alf.py', savedir, '--epochs_per_level', '1', '--run_last_layer_kd')
+    _check_saved(savedir, ['alf-2-uniform.pt', 'alf-2-logit-kd.pt'])
+    cmd = [sys.executable, os.path.join(SCRIPTS, 'run_alf.py'), '--model_savedir', str(savedir), '--num_fusion_samples',
+           '100', '--fusion_data', str(savedir / 'data.pt'), '--eval_data', str(savedir / 'data.pt'),
+           '--epochs_per_level', '1', '--use_weighted_loss']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and 'must match the size of tensor b (2)' in out.stderr

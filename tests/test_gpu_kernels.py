@@ -625,3 +625,81 @@ def test_xty_writes_into_caller_buffers(ops):
     assert torch.equal(buf, pack_gram(G, na, nb))
     with pytest.raises(ValueError):
         ops.xty(A, B, out=(G.float(), na, nb))
+
+
+# ---- symmetric eigendecomposition with a cutoff (the LS refit's factor step) --------------------------------------
+
+def _eig_cases():
+    rng = np.random.default_rng(0)
+    cases = {}
+    for n in (1, 2, 3, 4, 5, 17, 64, 65, 130, 257):
+        B = rng.standard_normal((n + 3, n))
+        cases[f'full{n}'] = (B.T @ B, 1e-13)
+    X = np.maximum(rng.standard_normal((900, 24)) @ rng.standard_normal((24, 200)) + 0.3 * rng.standard_normal((900, 200)), 0)
+    X = X.astype(np.float32).astype(np.float64)
+    X[:, ::7] = 0.0  # dead units: exactly zero rows / columns of the Gram
+    cases['relu200'] = (X.T @ X, (900 * 1.1920929e-07) ** 2)
+    L = rng.standard_normal((300, 40))
+    cases['lowrank300'] = (L @ L.T, 1e-10)
+    Q, _ = np.linalg.qr(rng.standard_normal((150, 150)))
+    cases['multiple150'] = (Q @ np.diag(np.r_[np.ones(40), np.full(40, 0.5), np.linspace(0.01, 0.4, 70)]) @ Q.T, 1e-6)
+    nw = 101
+    cases['wilkinson101'] = (np.diag(np.abs(np.arange(nw) - nw // 2).astype(float) + 3.0) + np.diag(np.ones(nw - 1), 1) +
+                             np.diag(np.ones(nw - 1), -1), 1e-9)
+    cases['diag50'] = (np.diag(np.linspace(0.0, 5.0, 50)), 1e-3)
+    blk = np.zeros((90, 90))
+    blk[:45, :45] = cases['full17'][0][:1, :1] * 0 + rng.standard_normal((45, 45))
+    blk[:45, :45] = blk[:45, :45] @ blk[:45, :45].T
+    blk[45:, 45:] = blk[:45, :45]   # two identical decoupled blocks: every eigenvalue is double, T splits
+    cases['twoblocks90'] = (blk, 1e-12)
+    return cases
+
+
+@pytest.mark.parametrize('name', sorted(_eig_cases()))
+def test_eigh_kept_matches_numpy(ops, name):
+    G, cutoff = _eig_cases()[name]
+    n = G.shape[0]
+    lam_ref, U = np.linalg.eigh(G)
+    keep = lam_ref > cutoff * lam_ref[-1]
+    lam, V = ops.eigh_kept(torch.from_numpy(G).cuda(), cutoff)
+    lam, V = lam.cpu().numpy(), V.cpu().numpy()
+    scale = max(abs(lam_ref[-1]), 1e-300)
+    # an eigenvalue within rounding of the threshold may fall on either side: compare away from it
+    margin = 1e-10 * scale
+    sure = lam_ref > cutoff * lam_ref[-1] + margin
+    assert sure.sum() <= lam.shape[0] <= (lam_ref > cutoff * lam_ref[-1] - margin).sum()
+    if lam.shape[0] == keep.sum():
+        np.testing.assert_allclose(lam, lam_ref[keep], rtol=0, atol=1e-12 * scale * max(n, 10))
+    assert V.shape == (n, lam.shape[0])
+    K = lam.shape[0]
+    assert np.abs(V.T @ V - np.eye(K)).max() < 1e-8
+    assert np.abs(G @ V - V * lam).max() < 1e-11 * scale * max(n, 10)
+    # the spectral function the refit needs: sum over kept of v v^T / lambda
+    if lam.shape[0] == keep.sum() and K > 0:
+        P = (V / lam) @ V.T
+        Pref = (U[:, keep] / lam_ref[keep]) @ U[:, keep].T
+        assert np.abs(P - Pref).max() <= 1e-7 * np.abs(Pref).max()
+
+
+@pytest.mark.parametrize('m,d', [(700, 577), (300, 1153), (2600, 130)])
+def test_ls_solve_with_own_eigensolver_matches_f64_pinv(ops, m, d):
+    """W = pinv(X) A through nif_eigh_kept_f64 (primal and dual forms) against numpy's SVD-based pinv in f64 with the
+    same cutoff; X has dead columns and a decaying spectrum so that the cutoff is active."""
+    rng = np.random.default_rng(m)
+    r = min(m, d)
+    U, _ = np.linalg.qr(rng.standard_normal((m, r)))
+    Vt, _ = np.linalg.qr(rng.standard_normal((d, r)))
+    sv = np.logspace(0, -7, r)
+    X = (U * sv) @ Vt.T
+    X[:, ::11] = 0.0
+    X = X.astype(np.float32)
+    A = rng.standard_normal((m, 9)).astype(np.float32)
+    rtol = max(m, d) * 1.1920928955078125e-07
+    ref = np.linalg.pinv(X.astype(np.float64), rcond=rtol) @ A.astype(np.float64)
+    sol = ops.ls_solve(torch.from_numpy(X).cuda(), torch.from_numpy(A).cuda())
+    s = np.linalg.svd(X.astype(np.float64), compute_uv=False)
+    gap = np.abs(s / s[0] - rtol).min()
+    assert gap > 1e-6 * rtol, 'test matrix has a singular value on the cutoff'
+    assert sol['rank'] == int((s > rtol * s[0]).sum())
+    W = sol['W'].cpu().numpy()
+    assert np.abs(W - ref).max() <= 2e-6 * np.abs(ref).max()
