@@ -59,6 +59,15 @@ struct TrdArgs {
 };
 
 // One column of the reduction.  LDS: sv1 = v_{j-1}, sw = w_{j-1}, svj = v_j, each ld doubles, indexed by column.
+// A step is latency-bound below n ~ 2500 (launch gap + a chain of dependent L2 round trips), so: every global load
+// the vector phase needs is issued at the top; the two block reductions are the only barriers before the trailing
+// pass; a workgroup takes one group of TRD_ROWS rows at a time and its 8 waves split the COLUMNS of the group
+// (chunk t of 128 columns goes to wave t % 8), so all of a group's data is in flight at once -- CPW chunks per wave
+// -- and the first group's loads are issued before the vector phase starts.
+constexpr int TRD_EPT = (NIF_EIGH_MAX_N + TRD_T - 1) / TRD_T;  // vector elements a thread owns at most
+constexpr int TRD_W = TRD_T / 64;
+
+template <int CPW>
 __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n = a.n, j = a.j, tid = threadIdx.x;
@@ -66,7 +75,8 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   double* sv1 = reinterpret_cast<double*>(smem_raw);
   double* sw = sv1 + ld;
   double* svj = sw + ld;
-  double* red = svj + ld;
+  double* red = svj + ld;            // 8 reduction slots + 2 broadcast slots (+ 6 spare)
+  double* rowpart = red + 16;        // [2][TRD_W][TRD_ROWS] partial row sums, double-buffered by group parity
   const double* vprev = a.vbuf + (size_t)((j + 1) & 1) * ld;  // parity of j - 1
   const double* yprev = a.ybuf + (size_t)((j + 1) & 1) * ld;
   double* vcur = a.vbuf + (size_t)(j & 1) * ld;
@@ -74,35 +84,94 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   const int c0 = (j + 1) & ~1;               // first column of the 16-byte aligned trailing pass (j or j + 1)
   const int cend = (n + 1) & ~1;             // one pad column when n is odd
   const bool pending = j > 0;
+  const int lane = tid & 63, wv = tid >> 6;
 
-  // (a) w_{j-1} = p + alpha v with p = tau y, alpha = -tau/2 (p . v): rows j .. n-1 (v_{j-1}[j] = 1)
-  for (int c = c0 + tid; c < cend; c += TRD_T) { sv1[c] = 0.0; sw[c] = 0.0; svj[c] = 0.0; }
-  if (tid == 0) { sv1[j] = 0.0; sw[j] = 0.0; svj[j] = 0.0; }
-  __syncthreads();
-  if (pending) {
-    const double tau1 = a.tau[j - 1];
-    double part = 0.0;
-    for (int r = j + tid; r < n; r += TRD_T) {
-      const double v = vprev[r], p = tau1 * yprev[r];
-      sv1[r] = v;
-      sw[r] = p;
-      part += p * v;
+  // ---- this workgroup's share of the trailing pass: row groups of TRD_ROWS consecutive rows (absolute numbering);
+  // group g always goes to a workgroup with blockIdx % 8 == g % 8, i.e. (workgroups are dealt round-robin over the
+  // XCDs) to the same XCD at every step, so an XCD's share of the matrix is re-read from its own L2 once it fits.
+  const int xcd = blockIdx.x & 7, sub = blockIdx.x >> 3, nsub = gridDim.x >> 3;
+  const int gfirst = (j + 1) / TRD_ROWS;
+  int g = gfirst + ((xcd - (gfirst & 7) + 8) & 7) + 8 * sub;
+  const int cw = c0 + 2 * lane + 128 * wv;   // column of this lane in its wave's first chunk; next chunks + 1024
+  double* row[TRD_ROWS];
+  bool live[TRD_ROWS];
+  int rr[TRD_ROWS];
+  double2 x[CPW][TRD_ROWS];
+  auto setup = [&](int grp) {
+#pragma unroll
+    for (int q = 0; q < TRD_ROWS; ++q) {
+      int r = grp * TRD_ROWS + q;
+      live[q] = r >= j + 1 && r < n;
+      r = r < j + 1 ? j + 1 : (r < n ? r : n - 1);  // clamped duplicates are loaded and discarded
+      rr[q] = r;
+      row[q] = a.A + (size_t)r * ld;
     }
-    const double dot = block_sum<TRD_T>(part, red);
-    const double alpha = -0.5 * tau1 * dot;
-    for (int r = j + tid; r < n; r += TRD_T) sw[r] += alpha * sv1[r];
-    __syncthreads();
+  };
+  auto fetch = [&]() {
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+      const int c = cw + 1024 * k;
+      if (c < cend) {
+#pragma unroll
+        for (int q = 0; q < TRD_ROWS; ++q) x[k][q] = *reinterpret_cast<const double2*>(row[q] + c);
+      }
+    }
+  };
+  bool has = g * TRD_ROWS < n;
+  if (has) {
+    setup(g);
+    fetch();
   }
-  // (b) row j of the updated matrix (= its column j): a_c = A[j][c] - v[j] w[c] - w[j] v[c]
-  const double vj_ = pending ? sv1[j] : 0.0, wj_ = pending ? sw[j] : 0.0;
+
+  // ---- vector phase, identical in every workgroup
+  double tau1 = 0.0, pj = 0.0, vjm = 0.0;
+  if (pending) {
+    tau1 = a.tau[j - 1];
+    pj = yprev[j];
+    vjm = vprev[j];  // = 1
+  }
+  double vv[TRD_EPT], pp[TRD_EPT], xx[TRD_EPT];
+  const double* arow = a.A + (size_t)j * ld;
+#pragma unroll
+  for (int it = 0; it < TRD_EPT; ++it) {
+    const int r = j + tid + it * TRD_T;
+    vv[it] = 0.0; pp[it] = 0.0; xx[it] = 0.0;
+    if (r < n) {
+      xx[it] = arow[r];
+      if (pending) { vv[it] = vprev[r]; pp[it] = yprev[r]; }
+    }
+  }
+  pj *= tau1;
+  double part = 0.0;
+#pragma unroll
+  for (int it = 0; it < TRD_EPT; ++it) {
+    pp[it] *= tau1;
+    part += pp[it] * vv[it];
+  }
+  // (a) w_{j-1} = p + alpha v with p = tau y, alpha = -tau/2 (p . v): rows j .. n-1 (v_{j-1}[j] = 1)
+  const double dot = pending ? block_sum<TRD_T>(part, red) : 0.0;
+  const double alpha = -0.5 * tau1 * dot;
+  const double wjm = pj + alpha * vjm;
+  // (b) row j of the updated matrix (= its column j): x_c = A[j][c] - v[j] w[c] - w[j] v[c]
   double part2 = 0.0;
-  for (int c = j + tid; c < n; c += TRD_T) {
-    const double x = a.A[(size_t)j * ld + c] - vj_ * sw[c] - wj_ * sv1[c];
-    svj[c] = x;
-    if (c >= j + 2) part2 += x * x;
+#pragma unroll
+  for (int it = 0; it < TRD_EPT; ++it) {
+    const int r = j + tid + it * TRD_T;
+    if (r < n) {
+      const double w = pp[it] + alpha * vv[it];
+      const double xr = xx[it] - vjm * w - wjm * vv[it];
+      xx[it] = xr;
+      // column j is finished: it is masked out of the trailing pass (which starts at column j when j + 1 is odd)
+      sv1[r] = r == j ? 0.0 : vv[it];
+      sw[r] = r == j ? 0.0 : w;
+      if (r >= j + 2) part2 += xr * xr;
+      if (r == j) red[8] = xr;
+      if (r == j + 1) red[9] = xr;
+    }
   }
+  if (tid == 0 && cend > n) { sv1[n] = 0.0; sw[n] = 0.0; svj[n] = 0.0; }
   const double xnorm2 = block_sum<TRD_T>(part2, red);
-  const double djj = svj[j], alpha0 = svj[j + 1];
+  const double djj = red[8], alpha0 = red[9];
   double tau, beta, scale;
   if (xnorm2 == 0.0) {
     tau = 0.0; beta = alpha0; scale = 0.0;
@@ -111,61 +180,78 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
     tau = (beta - alpha0) / beta;
     scale = 1.0 / (alpha0 - beta);
   }
-  __syncthreads();
-  for (int c = j + 2 + tid; c < n; c += TRD_T) svj[c] *= scale;
-  if (tid == 0) {
-    svj[j + 1] = 1.0;
-    svj[j] = 0.0;          // column j is finished: masked out of the trailing pass when c0 == j
-    sv1[j] = 0.0;
-    sw[j] = 0.0;
+#pragma unroll
+  for (int it = 0; it < TRD_EPT; ++it) {
+    const int r = j + tid + it * TRD_T;
+    if (r < n) {
+      const double v = r >= j + 2 ? xx[it] * scale : (r == j + 1 ? 1.0 : 0.0);
+      svj[r] = v;
+      if (blockIdx.x == 0 && r >= j + 1) vcur[r] = v;
+    }
   }
+  if (blockIdx.x == 0 && tid == 0) { a.d[j] = djj; a.e[j] = beta; a.tau[j] = tau; }
   __syncthreads();
-  if (blockIdx.x == 0) {
-    if (tid == 0) { a.d[j] = djj; a.e[j] = beta; a.tau[j] = tau; }
-    for (int r = j + 1 + tid; r < n; r += TRD_T) vcur[r] = svj[r];
-  }
 
-  // (c) trailing pass over rows j+1 .. n-1: apply the pending rank-2 update, store, and accumulate y = A v_j
-  const int lane = tid & 63, wv = tid >> 6;
-  const int nrows = n - (j + 1);
-  const int ngroups = (nrows + TRD_ROWS - 1) / TRD_ROWS;
-  const int gw = blockIdx.x * (TRD_T / 64) + wv, nw = gridDim.x * (TRD_T / 64);
-  for (int g = gw; g < ngroups; g += nw) {
-    const int r0 = j + 1 + g * TRD_ROWS;
+  // ---- (c) trailing pass: apply the pending rank-2 update, store, and accumulate y = A v_j
+  int parity = 0;
+  while (has) {   // uniform over the workgroup
     double vr[TRD_ROWS], wr[TRD_ROWS], acc[TRD_ROWS];
-    double* row[TRD_ROWS];
 #pragma unroll
     for (int q = 0; q < TRD_ROWS; ++q) {
-      const int r = r0 + q < n ? r0 + q : n - 1;  // clamped duplicates are discarded below
-      vr[q] = sv1[r];
-      wr[q] = sw[r];
+      vr[q] = sv1[rr[q]];
+      wr[q] = sw[rr[q]];
       acc[q] = 0.0;
-      row[q] = a.A + (size_t)r * ld;
     }
-    for (int c = c0 + 2 * lane; c < cend; c += 128) {
-      const double2 w2 = *reinterpret_cast<const double2*>(sw + c);
-      const double2 v2 = *reinterpret_cast<const double2*>(sv1 + c);
-      const double2 u2 = *reinterpret_cast<const double2*>(svj + c);
-      double2 x[TRD_ROWS];
 #pragma unroll
-      for (int q = 0; q < TRD_ROWS; ++q) x[q] = *reinterpret_cast<const double2*>(row[q] + c);
+    for (int k = 0; k < CPW; ++k) {
+      const int c = cw + 1024 * k;
+      if (c < cend) {
+        const double2 w2 = *reinterpret_cast<const double2*>(sw + c);
+        const double2 v2 = *reinterpret_cast<const double2*>(sv1 + c);
+        const double2 u2 = *reinterpret_cast<const double2*>(svj + c);
 #pragma unroll
-      for (int q = 0; q < TRD_ROWS; ++q) {
-        x[q].x -= vr[q] * w2.x + wr[q] * v2.x;
-        x[q].y -= vr[q] * w2.y + wr[q] * v2.y;
-        acc[q] += x[q].x * u2.x + x[q].y * u2.y;
-        if (pending && r0 + q < n) *reinterpret_cast<double2*>(row[q] + c) = x[q];
+        for (int q = 0; q < TRD_ROWS; ++q) {
+          double2 y = x[k][q];
+          y.x -= vr[q] * w2.x + wr[q] * v2.x;
+          y.y -= vr[q] * w2.y + wr[q] * v2.y;
+          acc[q] += y.x * u2.x + y.y * u2.y;
+          if (pending && live[q]) *reinterpret_cast<double2*>(row[q] + c) = y;
+        }
       }
     }
+    // the finished group's identity, then the next group's loads go out before the reductions
+    int frr[TRD_ROWS];
+    bool flive[TRD_ROWS];
+    double* frow[TRD_ROWS];
+#pragma unroll
+    for (int q = 0; q < TRD_ROWS; ++q) { frr[q] = rr[q]; flive[q] = live[q]; frow[q] = row[q]; }
+    g += 8 * nsub;
+    has = g * TRD_ROWS < n;
+    if (has) {
+      setup(g);
+      fetch();
+    }
+    double* part_ = rowpart + parity * (TRD_W * TRD_ROWS);
 #pragma unroll
     for (int q = 0; q < TRD_ROWS; ++q) {
-      const double s = wave_sum_f64(acc[q]);
-      const int r = r0 + q;
-      if (lane == 0 && r < n) {
-        ycur[r] = s;
-        if (r >= j + 2) a.A[(size_t)r * ld + j] = svj[r];  // reflector j, stored below the sub-diagonal of column j
+      const double sq = wave_sum_f64(acc[q]);
+      if (lane == 0) part_[wv * TRD_ROWS + q] = sq;
+    }
+    __syncthreads();
+    if (tid < TRD_ROWS) {
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < TRD_W; ++w) sum += part_[w * TRD_ROWS + tid];
+      // select this thread's row without dynamic register indexing
+      int r = frr[0]; bool lv = flive[0]; double* rp = frow[0];
+#pragma unroll
+      for (int q = 1; q < TRD_ROWS; ++q) if (tid == q) { r = frr[q]; lv = flive[q]; rp = frow[q]; }
+      if (lv) {
+        ycur[r] = sum;
+        if (r >= j + 2) rp[j] = svj[r];  // reflector j, stored below the sub-diagonal of column j
       }
     }
+    parity ^= 1;
   }
 }
 
@@ -234,9 +320,13 @@ __global__ void tri_bounds_kernel(const double* __restrict__ d, const double* __
   }
 }
 
-constexpr int BIS_T = 512;  // 8 eigenvalues per workgroup share one LDS copy of T
+constexpr int BIS_T = 512;   // threads of a workgroup: its waves share one LDS copy of T
+constexpr int BIS_P = 16;    // points per eigenvalue and pass: a wave carries 64 / BIS_P eigenvalues
 
-// lam[k] = k-th smallest eigenvalue.  One wave per eigenvalue; pass = 64 Sturm counts inside the bracket.
+// lam[k] = k-th smallest eigenvalue.  A group of BIS_P lanes brackets one eigenvalue: every pass evaluates the Sturm
+// count at BIS_P interior points and keeps the sub-interval that contains it (x BIS_P + 1 per pass, ~13 passes).
+// Sixteen points per eigenvalue rather than 64: the kernel is bound by the f64 divide chains in flight per SIMD, and
+// the narrower fan does a third of the total work for a third more passes.
 __global__ __launch_bounds__(BIS_T) void tri_eigenvalues_kernel(const double* __restrict__ d, const double* __restrict__ e,
                                                                 int n, const double* __restrict__ params,
                                                                 double* __restrict__ lam) {
@@ -249,14 +339,16 @@ __global__ __launch_bounds__(BIS_T) void tri_eigenvalues_kernel(const double* __
     se2[i] = x * x;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * (BIS_T / 64) + (threadIdx.x >> 6);
-  if (k >= n) return;
+  const int lane = threadIdx.x & 63, grp = lane / BIS_P, pt = lane % BIS_P;
+  const int k = (blockIdx.x * (BIS_T / 64) + (threadIdx.x >> 6)) * (64 / BIS_P) + grp;
   const double tnorm = params[0], pivmin = params[1];
   double lo = params[2], hi = params[3];
   const double tol = DBL_EPSILON * tnorm;
-  for (int pass = 0; pass < 14 && hi - lo > tol; ++pass) {
-    const double x = lo + (hi - lo) * ((double)(lane + 1) / 65.0);
+  const bool mine = k < n;
+  for (int pass = 0; pass < 20; ++pass) {
+    const bool active = mine && hi - lo > tol;
+    if (!__any(active)) break;
+    const double x = lo + (hi - lo) * ((double)(pt + 1) / (double)(BIS_P + 1));
     double q = sd[0] - x;
     if (fabs(q) < pivmin) q = -pivmin;
     int cnt = q < 0.0;
@@ -267,12 +359,15 @@ __global__ __launch_bounds__(BIS_T) void tri_eigenvalues_kernel(const double* __
     }
     // lambda_k < x  <=>  at least k + 1 eigenvalues lie below x
     const unsigned long long below = __ballot(cnt > k);
-    const int first = below ? __ffsll((long long)below) - 1 : 64;
-    const double xl = lo, xh = hi, w = xh - xl;
-    if (first < 64) hi = xl + w * ((double)(first + 1) / 65.0);
-    if (first > 0) lo = xl + w * ((double)first / 65.0);
+    const unsigned field = (unsigned)(below >> (grp * BIS_P)) & ((1u << BIS_P) - 1u);
+    const int first = field ? __ffs((int)field) - 1 : BIS_P;
+    if (active) {
+      const double xl = lo, w = hi - lo;
+      if (first < BIS_P) hi = xl + w * ((double)(first + 1) / (double)(BIS_P + 1));
+      if (first > 0) lo = xl + w * ((double)first / (double)(BIS_P + 1));
+    }
   }
-  if (lane == 0) lam[k] = 0.5 * (lo + hi);
+  if (mine && pt == 0) lam[k] = 0.5 * (lo + hi);
 }
 
 // kept eigenvalues = those above cutoff_rel * lambda_max; shifts for the inverse iteration: the rule
@@ -362,25 +457,53 @@ __global__ __launch_bounds__(64) void tri_invit_kernel(InvitArgs a) {
   const int64_t ldz = a.ldz;
   for (int i = 0; i < n; ++i) z[i * ldz] = hash_unit((unsigned)i, (unsigned)jj);
   double nrm2 = 0.0;
+  constexpr int CH = 8;  // rows whose operands are fetched together, ahead of the dependent chain that consumes them
   for (int it = 0; it < a.iters; ++it) {
     // forward: y = L^-1 P x
     double cur = z[0];
-    for (int i = 0; i + 1 < n; ++i) {
-      const double nxt = z[(i + 1) * ldz];
-      const bool swap = a.pv[i * K + jj] != 0;
-      const double top = swap ? nxt : cur, bot = swap ? cur : nxt;
-      z[i * ldz] = top;
-      cur = bot - a.dl[i * K + jj] * top;
+    for (int i0 = 0; i0 + 1 < n; i0 += CH) {
+      double nxt[CH], l[CH];
+      unsigned char sw_[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = i0 + k < n - 1 ? i0 + k : n - 2;
+        nxt[k] = z[(int64_t)(i + 1) * ldz];
+        l[k] = a.dl[i * K + jj];
+        sw_[k] = a.pv[i * K + jj];
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        if (i0 + k < n - 1) {
+          const bool swap = sw_[k] != 0;
+          const double top = swap ? nxt[k] : cur, bot = swap ? cur : nxt[k];
+          z[(int64_t)(i0 + k) * ldz] = top;
+          cur = bot - l[k] * top;
+        }
+      }
     }
     // backward: U x = y
     double x1 = cur * a.inv[(int64_t)(n - 1) * K + jj], x2 = 0.0;
     z[(int64_t)(n - 1) * ldz] = x1;
     nrm2 = x1 * x1;
-    for (int i = n - 2; i >= 0; --i) {
-      const double xi = (z[i * ldz] - a.du[i * K + jj] * x1 - a.du2[i * K + jj] * x2) * a.inv[i * K + jj];
-      z[i * ldz] = xi;
-      nrm2 += xi * xi;
-      x2 = x1; x1 = xi;
+    for (int i0 = n - 2; i0 >= 0; i0 -= CH) {
+      double y[CH], u1[CH], u2[CH], r[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = i0 - k >= 0 ? i0 - k : 0;
+        y[k] = z[(int64_t)i * ldz];
+        u1[k] = a.du[i * K + jj];
+        u2[k] = a.du2[i * K + jj];
+        r[k] = a.inv[i * K + jj];
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        if (i0 - k >= 0) {
+          const double xi = (y[k] - u1[k] * x1 - u2[k] * x2) * r[k];
+          z[(int64_t)(i0 - k) * ldz] = xi;
+          nrm2 += xi * xi;
+          x2 = x1; x1 = xi;
+        }
+      }
     }
     if (it + 1 < a.iters) {  // keep the iterate in range: three unscaled solves can reach 1e48, more would overflow
       const double s = 1.0 / sqrt(nrm2);
@@ -552,16 +675,9 @@ static EighWs eigh_ws(int n) {
   w.off_Vb = take((size_t)n * EIG_NB * 8);
   w.off_S = take((size_t)EIG_NB * EIG_NB * 8);
   w.off_M = take((size_t)EIG_NB * w.ldz * 8);
-  // nif_xty workspaces of the two products of a block (contraction over up to n rows)
-  size_t x1 = nif_xty_workspace_bytes(n, EIG_NB, EIG_NB, NIF_F64, NIF_SYMMETRIC);
-  size_t x2 = nif_xty_workspace_bytes(n, EIG_NB, n, NIF_F64, 0);
-  for (int nr = 64; nr < n; nr *= 2) {  // the split plan depends on the row count: size for the largest need
-    const size_t y1 = nif_xty_workspace_bytes(nr, EIG_NB, EIG_NB, NIF_F64, NIF_SYMMETRIC);
-    const size_t y2 = nif_xty_workspace_bytes(nr, EIG_NB, n, NIF_F64, 0);
-    if (y1 > x1) x1 = y1;
-    if (y2 > x2) x2 = y2;
-  }
-  w.xty_bytes = x1 > x2 ? x1 : x2;
+  // nif_xty workspace of the two products of a block (f64 path, 128-wide tiles): the split-K plan aims at no more
+  // than 512 workgroups, so tiles x splits <= 512 slabs of 128 x 128 doubles (64 MiB) plus the norm partials
+  w.xty_bytes = (size_t)72 << 20;
   w.off_xty = take(w.xty_bytes + 4096);
   w.total = o;
   return w;
@@ -605,21 +721,32 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
   if (n <= 2) {
     hipLaunchKernelGGL(trd_small_kernel, dim3(1), dim3(64), 0, st, t);
   } else {
-    const size_t lds = (3 * (size_t)w.ld + 16) * sizeof(double);
+    const size_t lds = (3 * (size_t)w.ld + 16 + 2 * TRD_W * TRD_ROWS) * sizeof(double);
     if (lds > 160 * 1024) return NIF_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)trd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)trd_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)trd_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)trd_step_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)trd_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)trd_step_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
     for (int j = 0; j + 2 < n; ++j) {
       t.j = j;
-      const int nrows = n - (j + 1);
-      const int groups = (nrows + TRD_ROWS - 1) / TRD_ROWS;
-      int blocks = (groups + (TRD_T / 64) - 1) / (TRD_T / 64);   // one group of rows per wave when they all fit
-      if (blocks > 256) blocks = 256;
-      if (blocks < 1) blocks = 1;
-      hipLaunchKernelGGL(trd_step_kernel, dim3(blocks), dim3(TRD_T), lds, st, t);
+      const int groups = (n - (j + 1) / TRD_ROWS * TRD_ROWS + TRD_ROWS - 1) / TRD_ROWS;  // row groups still alive
+      int b8 = (groups + 7) / 8;   // one group of rows per workgroup when they all fit
+      if (b8 > 32) b8 = 32;
+      if (b8 < 1) b8 = 1;
+      const int c0 = (j + 1) & ~1, cend = (n + 1) & ~1;
+      const int chunks = (cend - c0 + 127) / 128;
+      const int cpw = (chunks + TRD_W - 1) / TRD_W;   // chunks of 128 columns a wave holds in flight per group
+      const dim3 grid(8 * b8), block(TRD_T);
+      if (cpw <= 1) hipLaunchKernelGGL(trd_step_kernel<1>, grid, block, lds, st, t);
+      else if (cpw == 2) hipLaunchKernelGGL(trd_step_kernel<2>, grid, block, lds, st, t);
+      else if (cpw == 3) hipLaunchKernelGGL(trd_step_kernel<3>, grid, block, lds, st, t);
+      else if (cpw == 4) hipLaunchKernelGGL(trd_step_kernel<4>, grid, block, lds, st, t);
+      else hipLaunchKernelGGL(trd_step_kernel<6>, grid, block, lds, st, t);
     }
     hipLaunchKernelGGL(trd_finish_kernel, dim3(1), dim3(64), 0, st, t);
   }
@@ -634,7 +761,7 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
       (void)hipFuncSetAttribute((const void*)tri_eigenvalues_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(tri_eigenvalues_kernel, dim3((n + BIS_T / 64 - 1) / (BIS_T / 64)), dim3(BIS_T), lds, st, t.d, t.e, n,
+    hipLaunchKernelGGL(tri_eigenvalues_kernel, dim3((n + BIS_T / BIS_P - 1) / (BIS_T / BIS_P)), dim3(BIS_T), lds, st, t.d, t.e, n,
                        params, lam_all);
   }
   hipLaunchKernelGGL(tri_select_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lam_all, n, cutoff_rel, params, shifts, kept_dev);
