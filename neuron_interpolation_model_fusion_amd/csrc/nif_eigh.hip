@@ -353,7 +353,12 @@ __global__ __launch_bounds__(BIS_T) void tri_eigenvalues_kernel(const double* __
     if (fabs(q) < pivmin) q = -pivmin;
     int cnt = q < 0.0;
     for (int i = 1; i < n; ++i) {
-      q = sd[i] - x - se2[i - 1] / q;
+      // e^2 / q through the hardware reciprocal (about 24 bits) and two Newton steps: the full IEEE divide expansion
+      // is what bounds this kernel, and |q| >= pivmin here so no special cases arise
+      double r = __builtin_amdgcn_rcp(q);
+      r = fma(fma(-q, r, 1.0), r, r);
+      r = fma(fma(-q, r, 1.0), r, r);
+      q = sd[i] - x - se2[i - 1] * r;
       if (fabs(q) < pivmin) q = -pivmin;
       cnt += q < 0.0;
     }
@@ -416,9 +421,11 @@ struct InvitArgs {
 
 // One lane per kept eigenvector; the lanes of a wave walk the rows together (uniform loads of d, e; coalesced
 // stores of the factors).
+constexpr int INV_VPW = 16;  // eigenvectors per wave: the solves are latency chains and only K / 64 full waves would
+                             // exist chip-wide, so a wave carries 16 vectors (128-byte row pieces) and 4x as many run
 __global__ __launch_bounds__(64) void tri_invit_kernel(InvitArgs a) {
-  const int jj = blockIdx.x * 64 + threadIdx.x;
-  if (jj >= a.K) return;
+  const int jj = blockIdx.x * INV_VPW + threadIdx.x;
+  if (threadIdx.x >= INV_VPW || jj >= a.K) return;
   const int n = a.n;
   const int64_t K = a.K;
   const double lam = a.shifts[jj];
@@ -457,89 +464,145 @@ __global__ __launch_bounds__(64) void tri_invit_kernel(InvitArgs a) {
   const int64_t ldz = a.ldz;
   for (int i = 0; i < n; ++i) z[i * ldz] = hash_unit((unsigned)i, (unsigned)jj);
   double nrm2 = 0.0;
-  constexpr int CH = 8;  // rows whose operands are fetched together, ahead of the dependent chain that consumes them
+  // The solves are chains of dependent FMAs fed by strided loads; only a few dozen waves exist chip-wide, so nothing
+  // hides a load's round trip except the wave itself: operands travel in chunks of CH rows, and the next chunk's
+  // loads are always issued before the current chunk's chain runs (two register sets, loop unrolled by two).
+  constexpr int CH = 8;
+  struct Fwd { double nxt[CH], l[CH]; unsigned char sw[CH]; };
+  struct Bwd { double y[CH], u1[CH], u2[CH], r[CH]; };
+  auto load_f = [&](Fwd& f, int i0) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      int i = i0 + k;
+      i = i < n - 1 ? i : n - 2;
+      i = i < 0 ? 0 : i;
+      f.nxt[k] = z[(int64_t)(i + 1 < n ? i + 1 : n - 1) * ldz];
+      f.l[k] = a.dl[i * K + jj];
+      f.sw[k] = a.pv[i * K + jj];
+    }
+  };
+  auto load_b = [&](Bwd& f, int i0) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int i = i0 - k >= 0 ? i0 - k : 0;
+      f.y[k] = z[(int64_t)i * ldz];
+      f.u1[k] = a.du[i * K + jj];
+      f.u2[k] = a.du2[i * K + jj];
+      f.r[k] = a.inv[i * K + jj];
+    }
+  };
   for (int it = 0; it < a.iters; ++it) {
     // forward: y = L^-1 P x
     double cur = z[0];
-    for (int i0 = 0; i0 + 1 < n; i0 += CH) {
-      double nxt[CH], l[CH];
-      unsigned char sw_[CH];
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int i = i0 + k < n - 1 ? i0 + k : n - 2;
-        nxt[k] = z[(int64_t)(i + 1) * ldz];
-        l[k] = a.dl[i * K + jj];
-        sw_[k] = a.pv[i * K + jj];
-      }
+    auto run_f = [&](const Fwd& f, int i0) {
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         if (i0 + k < n - 1) {
-          const bool swap = sw_[k] != 0;
-          const double top = swap ? nxt[k] : cur, bot = swap ? cur : nxt[k];
+          const bool swap = f.sw[k] != 0;
+          const double top = swap ? f.nxt[k] : cur, bot = swap ? cur : f.nxt[k];
           z[(int64_t)(i0 + k) * ldz] = top;
-          cur = bot - l[k] * top;
+          cur = bot - f.l[k] * top;
         }
+      }
+    };
+    if (n > 1) {
+      Fwd fa, fb;
+      load_f(fa, 0);
+      for (int i0 = 0; i0 < n - 1; i0 += 2 * CH) {
+        if (i0 + CH < n - 1) load_f(fb, i0 + CH);
+        run_f(fa, i0);
+        if (i0 + 2 * CH < n - 1) load_f(fa, i0 + 2 * CH);
+        if (i0 + CH < n - 1) run_f(fb, i0 + CH);
       }
     }
     // backward: U x = y
     double x1 = cur * a.inv[(int64_t)(n - 1) * K + jj], x2 = 0.0;
     z[(int64_t)(n - 1) * ldz] = x1;
     nrm2 = x1 * x1;
-    for (int i0 = n - 2; i0 >= 0; i0 -= CH) {
-      double y[CH], u1[CH], u2[CH], r[CH];
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int i = i0 - k >= 0 ? i0 - k : 0;
-        y[k] = z[(int64_t)i * ldz];
-        u1[k] = a.du[i * K + jj];
-        u2[k] = a.du2[i * K + jj];
-        r[k] = a.inv[i * K + jj];
-      }
+    auto run_b = [&](const Bwd& f, int i0) {
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         if (i0 - k >= 0) {
-          const double xi = (y[k] - u1[k] * x1 - u2[k] * x2) * r[k];
+          const double xi = (f.y[k] - f.u1[k] * x1 - f.u2[k] * x2) * f.r[k];
           z[(int64_t)(i0 - k) * ldz] = xi;
           nrm2 += xi * xi;
           x2 = x1; x1 = xi;
         }
       }
+    };
+    if (n > 1) {
+      Bwd ba, bb;
+      load_b(ba, n - 2);
+      for (int i0 = n - 2; i0 >= 0; i0 -= 2 * CH) {
+        if (i0 - CH >= 0) load_b(bb, i0 - CH);
+        run_b(ba, i0);
+        if (i0 - 2 * CH >= 0) load_b(ba, i0 - 2 * CH);
+        if (i0 - CH >= 0) run_b(bb, i0 - CH);
+      }
     }
     if (it + 1 < a.iters) {  // keep the iterate in range: three unscaled solves can reach 1e48, more would overflow
       const double s = 1.0 / sqrt(nrm2);
+#pragma unroll 8
       for (int i = 0; i < n; ++i) z[i * ldz] *= s;
     }
   }
   const double s = 1.0 / sqrt(nrm2);
+#pragma unroll 8
   for (int i = 0; i < n; ++i) z[i * ldz] *= s;
 }
 
-// Modified Gram-Schmidt (two passes) inside every maximal run of kept eigenvalues whose neighbours are closer than
-// ortol_rel * |T|: one wave per run, started by the run's first member; other waves leave at once.
-__global__ __launch_bounds__(64) void tri_mgs_kernel(const double* __restrict__ lam_kept, int K, int n,
-                                                     const double* __restrict__ params, double ortol_rel, double* Z,
-                                                     int64_t ldz) {
-  const int j0 = blockIdx.x, lane = threadIdx.x;
+// Re-orthogonalisation inside every maximal run of kept eigenvalues whose neighbours are closer than
+// ortol_rel * |T| (inverse iteration leaves an angle error ~ eps |T| / gap between such neighbours): classical
+// Gram-Schmidt applied twice per vector ("twice is enough"), one workgroup per run, started by the run's first
+// member; the other workgroups leave at once.  Phase 1 forms all inner products with the earlier members at once
+// (threads along the members, so the row-major Z is read in contiguous pieces), phase 2 subtracts them row by row.
+constexpr int ORT_T = 256;
+__global__ __launch_bounds__(ORT_T) void tri_ortho_kernel(const double* __restrict__ lam_kept, int K, int n,
+                                                          const double* __restrict__ params, double ortol_rel,
+                                                          double* Z, int64_t ldz) {
+  __shared__ double coef[NIF_EIGH_MAX_N];
+  __shared__ double part[ORT_T / 64][64];
+  __shared__ double red[ORT_T / 64 + 1];
+  const int j0 = blockIdx.x, tid = threadIdx.x;
   if (j0 >= K) return;
   const double ortol = ortol_rel * params[0];
   if (j0 > 0 && lam_kept[j0] - lam_kept[j0 - 1] <= ortol) return;    // not the first of its run
   int j1 = j0;
   while (j1 + 1 < K && lam_kept[j1 + 1] - lam_kept[j1] <= ortol) ++j1;
   if (j1 == j0) return;
-  for (int aidx = j0 + 1; aidx <= j1; ++aidx) {
+  const int tx = tid & 63, ty = tid >> 6;
+  for (int av = j0 + 1; av <= j1; ++av) {
+    const int nbv = av - j0;
     for (int rep = 0; rep < 2; ++rep) {
-      for (int b = j0; b < aidx; ++b) {
-        double dot = 0.0;
-        for (int i = lane; i < n; i += 64) dot += Z[i * ldz + b] * Z[i * ldz + aidx];
-        dot = wave_sum_f64(dot);
-        for (int i = lane; i < n; i += 64) Z[i * ldz + aidx] -= dot * Z[i * ldz + b];
+      for (int b0 = 0; b0 < nbv; b0 += 64) {
+        const int bb = b0 + tx;
+        double acc = 0.0;
+        if (bb < nbv)
+          for (int i = ty; i < n; i += ORT_T / 64) acc += Z[(int64_t)i * ldz + j0 + bb] * Z[(int64_t)i * ldz + av];
+        part[ty][tx] = acc;
+        __syncthreads();
+        if (ty == 0 && bb < nbv) {
+          double sum = 0.0;
+#pragma unroll
+          for (int q = 0; q < ORT_T / 64; ++q) sum += part[q][tx];
+          coef[bb] = sum;
+        }
+        __syncthreads();
       }
+      for (int i = tid; i < n; i += ORT_T) {
+        const double* zr = Z + (int64_t)i * ldz + j0;
+        double acc = 0.0;
+        for (int bb = 0; bb < nbv; ++bb) acc += coef[bb] * zr[bb];
+        Z[(int64_t)i * ldz + av] -= acc;
+      }
+      __syncthreads();
     }
     double nn = 0.0;
-    for (int i = lane; i < n; i += 64) nn += Z[i * ldz + aidx] * Z[i * ldz + aidx];
-    nn = wave_sum_f64(nn);
-    const double s = 1.0 / sqrt(nn);
-    for (int i = lane; i < n; i += 64) Z[i * ldz + aidx] *= s;
+    for (int i = tid; i < n; i += ORT_T) { const double v = Z[(int64_t)i * ldz + av]; nn += v * v; }
+    nn = block_sum<ORT_T>(nn, red);
+    const double sc = 1.0 / sqrt(nn);
+    for (int i = tid; i < n; i += ORT_T) Z[(int64_t)i * ldz + av] *= sc;
+    __syncthreads();
   }
 }
 
@@ -559,28 +622,54 @@ __global__ void bt_extract_kernel(const double* __restrict__ A, int64_t ld, int 
   Vb[(size_t)rr * EIG_NB + l] = v;
 }
 
-// Y = T M with T^-1 = diag(1/tau) + striu(S): back substitution, one thread per column of M (nbk x K, ld ldm),
-// in place; the 64-column slice of M a workgroup owns is staged in LDS.  tau = 0 (identity reflector) gives a
-// zero row.
-__global__ __launch_bounds__(64) void bt_trsolve_kernel(const double* __restrict__ S, int64_t lds_,
-                                                        const double* __restrict__ tau, int nbk, double* __restrict__ M,
-                                                        int64_t ldm, int K) {
-  __shared__ double sS[EIG_NB * EIG_NB];
-  __shared__ double sY[EIG_NB][64 + 1];
+// T = (diag(1/tau) + striu(S))^-1, the triangular factor of the block reflector I - V T V^T.  Thread c owns column c
+// of T in registers (fully unrolled back substitution, entries below the diagonal stay zero), every thread walks the
+// same (i, l) sequence so S[i][l] is one LDS broadcast.  tau = 0 (identity reflector) gives a zero row and column.
+__global__ __launch_bounds__(64) void bt_tfactor_kernel(const double* __restrict__ S, int64_t lds_,
+                                                        const double* __restrict__ tau, int nbk, double* __restrict__ T) {
+  __shared__ __attribute__((aligned(16))) double sS[EIG_NB][EIG_NB];
   __shared__ double st[EIG_NB];
-  const int tid = threadIdx.x;
-  for (int q = tid; q < nbk * nbk; q += 64) sS[(q / nbk) * EIG_NB + (q % nbk)] = S[(size_t)(q / nbk) * lds_ + (q % nbk)];
-  for (int q = tid; q < nbk; q += 64) st[q] = tau[q];
-  const int c = blockIdx.x * 64 + tid;
-  for (int i = 0; i < nbk; ++i) sY[i][tid] = c < K ? M[(size_t)i * ldm + c] : 0.0;
-  __syncthreads();
-  for (int i = nbk - 1; i >= 0; --i) {
-    double s = sY[i][tid];
-    for (int l = i + 1; l < nbk; ++l) s -= sS[i * EIG_NB + l] * sY[l][tid];
-    sY[i][tid] = st[i] * s;
+  const int c = threadIdx.x;
+  for (int q = c; q < EIG_NB * EIG_NB; q += 64) {
+    const int i = q / EIG_NB, l = q % EIG_NB;
+    sS[i][l] = (i < nbk && l < nbk) ? S[(size_t)i * lds_ + l] : 0.0;
   }
-  if (c < K)
-    for (int i = 0; i < nbk; ++i) M[(size_t)i * ldm + c] = sY[i][tid];
+  st[c] = c < nbk ? tau[c] : 0.0;
+  __syncthreads();
+  double t[EIG_NB];
+#pragma unroll
+  for (int l = 0; l < EIG_NB; ++l) t[l] = l == c ? st[c] : 0.0;
+#pragma unroll
+  for (int i = EIG_NB - 2; i >= 0; --i) {
+    double sum = 0.0;
+#pragma unroll
+    for (int l = i + 1; l < EIG_NB; ++l) sum += sS[i][l] * t[l];
+    const double v = -st[i] * sum;
+    t[i] = i < c ? v : t[i];
+  }
+#pragma unroll
+  for (int l = 0; l < EIG_NB; ++l) T[(size_t)l * EIG_NB + c] = t[l];
+}
+
+// Y = T M in place (T upper triangular EIG_NB x EIG_NB, M: EIG_NB x K with rows >= nbk treated as zero): thread per
+// column of M, the column in registers, T[i][l] an LDS broadcast.
+__global__ __launch_bounds__(64) void bt_tm_kernel(const double* __restrict__ T, int nbk, double* __restrict__ M,
+                                                   int64_t ldm, int K) {
+  __shared__ __attribute__((aligned(16))) double sT[EIG_NB][EIG_NB];
+  for (int q = threadIdx.x; q < EIG_NB * EIG_NB; q += 64) sT[q / EIG_NB][q % EIG_NB] = T[q];
+  __syncthreads();
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= K) return;
+  double m[EIG_NB];
+#pragma unroll
+  for (int l = 0; l < EIG_NB; ++l) m[l] = l < nbk ? M[(size_t)l * ldm + c] : 0.0;
+#pragma unroll
+  for (int i = 0; i < EIG_NB; ++i) {
+    double y = 0.0;
+#pragma unroll
+    for (int l = i; l < EIG_NB; ++l) y += sT[i][l] * m[l];
+    if (i < nbk) M[(size_t)i * ldm + c] = y;
+  }
 }
 
 // Z[j0+1+rr][c] -= sum_l Vb[rr][l] Y[l][c]: 64 x 64 tiles, 256 threads, 4 x 4 per thread, l in two halves of 32
@@ -649,7 +738,7 @@ static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct EighWs {
   size_t off_A, off_vbuf, off_ybuf, off_d, off_e, off_tau, off_lam, off_shift, off_params, off_kept;
-  size_t off_fac, off_pv, off_Vb, off_S, off_M, off_xty, total;
+  size_t off_fac, off_pv, off_Vb, off_S, off_T, off_M, off_xty, total;
   int64_t ld, ldz;
   size_t xty_bytes;
 };
@@ -674,6 +763,7 @@ static EighWs eigh_ws(int n) {
   w.off_pv = take((size_t)n * n);
   w.off_Vb = take((size_t)n * EIG_NB * 8);
   w.off_S = take((size_t)EIG_NB * EIG_NB * 8);
+  w.off_T = take((size_t)EIG_NB * EIG_NB * 8);
   w.off_M = take((size_t)EIG_NB * w.ldz * 8);
   // nif_xty workspace of the two products of a block (f64 path, 128-wide tiles): the split-K plan aims at no more
   // than 512 workgroups, so tiles x splits <= 512 slabs of 128 x 128 doubles (64 MiB) plus the norm partials
@@ -785,8 +875,8 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
   ia.Z = V;
   ia.ldz = ldv;
   ia.iters = 3;
-  hipLaunchKernelGGL(tri_invit_kernel, dim3((K + 63) / 64), dim3(64), 0, st, ia);
-  hipLaunchKernelGGL(tri_mgs_kernel, dim3(K), dim3(64), 0, st, lam, K, n, params, 1e-9, V, ldv);
+  hipLaunchKernelGGL(tri_invit_kernel, dim3((K + INV_VPW - 1) / INV_VPW), dim3(64), 0, st, ia);
+  hipLaunchKernelGGL(tri_ortho_kernel, dim3(K), dim3(ORT_T), 0, st, lam, K, n, params, 1e-9, V, ldv);
   if (!launch_ok()) return NIF_ERR_LAUNCH;
 
   // 4. back-transformation, last block of reflectors first
@@ -794,6 +884,7 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
     double* Vb = reinterpret_cast<double*>(b + w.off_Vb);
     double* S = reinterpret_cast<double*>(b + w.off_S);
     double* M = reinterpret_cast<double*>(b + w.off_M);
+    double* Tm = reinterpret_cast<double*>(b + w.off_T);
     void* xws = b + w.off_xty;
     const int nref = n - 2;
     const int nblk = (nref + EIG_NB - 1) / EIG_NB;
@@ -809,8 +900,8 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
       rc = nif_xty(Vb, EIG_NB, Zs, ldv, nr, nbk, K, NIF_F64, NIF_F64, 0, M, w.ldz, nullptr, nullptr, xws, w.xty_bytes,
                    stream);
       if (rc != NIF_OK) return rc;
-      hipLaunchKernelGGL(bt_trsolve_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, (int64_t)EIG_NB, t.tau + j0, nbk, M,
-                         w.ldz, K);
+      hipLaunchKernelGGL(bt_tfactor_kernel, dim3(1), dim3(64), 0, st, S, (int64_t)EIG_NB, t.tau + j0, nbk, Tm);
+      hipLaunchKernelGGL(bt_tm_kernel, dim3((K + 63) / 64), dim3(64), 0, st, Tm, nbk, M, w.ldz, K);
       hipLaunchKernelGGL(bt_update_kernel, dim3((K + 63) / 64, (nr + 63) / 64), dim3(256), 0, st, Vb, M, w.ldz, nr, nbk, K,
                          Zs, ldv);
     }
