@@ -300,6 +300,30 @@ size_t nif_eigh_kept_workspace_bytes(int n);
 int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cutoff_rel, double* lam, double* V, int64_t ldv,
                       int32_t* kept_host, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- least-squares refit W = pinv(X) A: hf_kf.py:213 (`torch.linalg.pinv(X)`), :233-234 and :377,:397
+ * (`pinv @ acts`) -------------------------------------------------------------------------------------------
+ * X: m x d f32 (ldx) design matrix of the layer (im2col rows + ones column), A: m x N f32 (lda) pre-activations of
+ * all models side by side.  Outputs, all f64: W (d x N, ldw) = pinv(X) A with torch.linalg.pinv's default cutoff for
+ * f32 data (singular values <= max(m, d) * eps_f32 * sigma_max dropped), R (d x N, ldr) = X^T A and na (N) = squared
+ * column norms of A (what nif_cost_hf and the k-means Gram are built from), *rank_host (HOST int) = number of singular
+ * values kept.  m >= d: normal equations G = X^T X; m < d: dual form through X X^T (minimum-norm solution), unless
+ * NIF_LSQ_PRIMAL.  NIF_LSQ_NORMALIZE first scales A's columns to unit norm (norm_acts, fusion_utils.py:38-40; R and na
+ * come back for the scaled columns).  Gram builds and products on the f64 matrix cores, factorisation by
+ * nif_eigh_kept_f64; the call blocks the host twice on `stream` (live-column count, kept count). */
+#define NIF_LSQ_NORMALIZE 1
+#define NIF_LSQ_PRIMAL 2
+size_t nif_lsq_refit_workspace_bytes(int64_t m, int d, int N, int flags);
+int nif_lsq_refit_f32(const float* X, int64_t ldx, int64_t m, int d, const float* A, int64_t lda, int N, int flags,
+                      double* W, int64_t ldw, double* R, int64_t ldr, double* na, int32_t* rank_host, void* ws,
+                      size_t ws_bytes, void* stream);
+/* The solve alone, for callers that reduce the normal equations over several GPUs first (sample-sharded fusion:
+ * every rank all-reduces its partial G = X^T X (d x d) and R = X^T A (d x N), then calls this): W = G^+ R keeping
+ * the eigenpairs above cutoff_rel * lambda_max (cutoff_rel = (max(m, d) eps_f32)^2 for pinv's rule).  Rows / columns
+ * of G whose diagonal is zero are taken out first and give zero rows of W. */
+size_t nif_lsq_solve_workspace_bytes(int d, int N);
+int nif_lsq_solve_f64(const double* G, int64_t ldg, const double* R, int64_t ldr, int d, int N, double cutoff_rel,
+                      double* W, int64_t ldw, int32_t* rank_host, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ NIF_LAP_RESUME = 4
 NIF_LAP_BUDGET_SHIFT = 8
 NIF_EMD_MAX_N = 8192
 NIF_EIGH_MAX_N = 6144
+NIF_LSQ_NORMALIZE, NIF_LSQ_PRIMAL = 1, 2
 NIF_EMD_EDGES_GLOBAL = 1
 NIF_ERR_WORKSPACE = -2
 
@@ -64,6 +65,12 @@ SIGNATURES = {
     'nif_wmse_backward': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     'nif_lap_count_tight_f32': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _c.c_double, _vp, _vp]),
     'nif_im2row_f32': (_i32, [_vp, _i64] + [_i32] * 10 + [_vp, _i64, _vp]),
+    'nif_lsq_refit_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
+    'nif_lsq_refit_f32': (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp,
+                                 _c.POINTER(_c.c_int32), _vp, _sz, _vp]),
+    'nif_lsq_solve_workspace_bytes': (_sz, [_i32, _i32]),
+    'nif_lsq_solve_f64': (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _c.c_double, _vp, _i64, _c.POINTER(_c.c_int32), _vp, _sz,
+                                 _vp]),
     'nif_eigh_kept_workspace_bytes': (_sz, [_i32]),
     'nif_eigh_kept_f64': (_i32, [_vp, _i64, _i32, _c.c_double, _vp, _vp, _i64, _c.POINTER(_c.c_int32), _vp, _sz, _vp]),
 }

@@ -316,63 +316,54 @@ def ls_solve(X, A, normalize=False):
       m >= d:  G = X^T X, R = X^T A (f64 MFMA);  G = V L V^T;  W = V L_kept^-1 V^T R
       m <  d:  K = X X^T;  K = U L U^T;  W = X^T (U L_kept^-1 U^T A)          (dual form)
 
-    The Gram build and every dense product run on nif_xty; the symmetric eigendecomposition of the normal matrix is
-    nif_eigh_kept_f64 (hand-written kernels: no vendor solver on the path).
+    One C call (nif_lsq_refit_f32): Gram builds and products on nif_xty, factorisation by nif_eigh_kept_f64 -- no
+    vendor solver on the path.  Inside a parallel.SampleSharding context the normal equations are all-reduced over
+    the ranks first (primal form, GLOBAL row count in the cutoff) and nif_lsq_solve_f64 finishes.
     normalize=True scales A's columns to unit norm first (fusion_utils.py:38-40).
     Returns dict(W (d x N f64), R = X^T A (d x N f64), na = squared column norms of A (N f64), rank).
     """
     _need_gpu(X, A)
     m, d = X.shape
+    N = A.shape[1]
     from .parallel import SampleSharding
     sharded = SampleSharding._active is not None
-    if sharded:  # m is the GLOBAL row count for pinv's cutoff; the dual form needs every row locally
-        import torch.distributed as dist
-        mt = torch.tensor([m], device=X.device, dtype=torch.int64)
-        dist.all_reduce(mt, group=SampleSharding._active.group)
-        m = int(mt.item())
+    rank = ctypes.c_int32(0)
+    if not sharded:
+        X, A = _mat(X.float(), 'X'), _mat(A.float(), 'A')
+        flags = _lib.NIF_LSQ_NORMALIZE if normalize else 0
+        with torch.cuda.device(X.device):
+            W = torch.empty((d, N), dtype=torch.float64, device=X.device)
+            R = torch.empty((d, N), dtype=torch.float64, device=X.device)
+            na = torch.empty(N, dtype=torch.float64, device=X.device)
+            nbytes = lib.nif_lsq_refit_workspace_bytes(m, d, N, flags)
+            if nbytes == 0:
+                raise _lib.NifError(f'ls_solve: min(m, d) = {min(m, d)} exceeds NIF_EIGH_MAX_N = {_lib.NIF_EIGH_MAX_N}')
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+            check(lib.nif_lsq_refit_f32(_ptr(X), _ld(X), m, d, _ptr(A), _ld(A), N, flags, _ptr(W), N, _ptr(R), N,
+                                        _ptr(na), ctypes.byref(rank), _ptr(ws), nbytes, _stream()), 'nif_lsq_refit_f32')
+        return dict(W=W, R=R, na=na, rank=rank.value)
+    # sample-sharded: m is the GLOBAL row count for pinv's cutoff, and the dual form would need every row locally,
+    # so the d x d normal equations are reduced and solved on every rank (identical inputs -> identical results)
+    import torch.distributed as dist
+    mt = torch.tensor([m], device=X.device, dtype=torch.int64)
+    dist.all_reduce(mt, group=SampleSharding._active.group)
+    m = int(mt.item())
     R, _, na = xty(X, A, acc='f64', rows_sharded=True)
     if normalize:
-        inv = 1.0 / na.sqrt()
-        R = R * inv[None, :]
+        R = R / na.sqrt()[None, :]
         na = torch.ones_like(na)
+    G, _, _ = xty(X, None, acc='f64', norms=False, rows_sharded=True)
+    G, R = G.contiguous(), R.contiguous()
     rtol = max(m, d) * _EPS32
-    if m >= d or sharded:
-        G, _, _ = xty(X, None, acc='f64', norms=False, rows_sharded=True)
-        # Deflation: a column of X that is exactly zero (a dead ReLU channel of the previous level, times its
-        # kernel taps) is an eigenvector of G with eigenvalue 0 -- pinv drops it and its row of W is 0.  Taking
-        # those out first leaves the same kept eigenpairs on a smaller matrix (eigh is ~d^3).
-        live = G.diagonal() > 0
-        idx = None
-        if int(live.sum().item()) < d:
-            idx = live.nonzero().squeeze(1)
-            G = G.index_select(0, idx).index_select(1, idx)
-        rank = 0
-        if G.shape[0] > 0:
-            lam, V = eigh_kept(G, rtol * rtol)   # only the eigenpairs pinv keeps
-            rank = lam.shape[0]
-        if rank > 0:
-            Z, _, _ = xty(V, R if idx is None else R.index_select(0, idx), acc='f64', norms=False)   # V^T R
-            Z = Z / lam[:, None]
-            W, _, _ = xty(V, Z, acc='f64', trans_a=True, norms=False)   # V Z
-        else:  # X = 0: pinv(X) = 0
-            W = torch.zeros((G.shape[0], R.shape[1]), dtype=torch.float64, device=X.device)
-        if idx is not None:
-            W = torch.zeros((d, W.shape[1]), dtype=W.dtype, device=W.device).index_copy_(0, idx, W)
-    else:
-        K, _, _ = xty(X, None, acc='f64', trans_a=True, norms=False)  # X X^T
-        lam, U = eigh_kept(K, rtol * rtol)
-        rank = lam.shape[0]
-        if rank > 0:
-            A64 = A.double()
-            if normalize:
-                A64 = A64 * inv[None, :]
-            Z, _, _ = xty(U, A64, acc='f64', norms=False)        # U^T A
-            Z = Z / lam[:, None]
-            Y, _, _ = xty(U, Z, acc='f64', trans_a=True, norms=False)   # U Z  (m x N)
-            W, _, _ = xty(X.double(), Y, acc='f64', norms=False)        # X^T Y
-        else:
-            W = torch.zeros((d, A.shape[1]), dtype=torch.float64, device=X.device)
-    return dict(W=W, R=R, na=na, rank=rank)
+    with torch.cuda.device(X.device):
+        W = torch.empty((d, N), dtype=torch.float64, device=X.device)
+        nbytes = lib.nif_lsq_solve_workspace_bytes(d, N)
+        if nbytes == 0:
+            raise _lib.NifError(f'ls_solve: d = {d} exceeds NIF_EIGH_MAX_N = {_lib.NIF_EIGH_MAX_N}')
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+        check(lib.nif_lsq_solve_f64(_ptr(G), d, _ptr(R), N, d, N, rtol * rtol, _ptr(W), N, ctypes.byref(rank), _ptr(ws),
+                                    nbytes, _stream()), 'nif_lsq_solve_f64')
+    return dict(W=W, R=R, na=na, rank=rank.value)
 
 
 def refit_pairs(W, col, s0, s1, n0):
