@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- fused levels/sec of the per-level matching-and-refit path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (default workload: C2 level throughput)
+  python bench.py --workload c1|c3|c4 [--steps K]           (end-to-end fusion wall-clock, one GPU: bench_e2e.py)
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (BASELINE.json configs[1], SURVEY section 8d "C2"): one OTFusion activation-mode
@@ -42,6 +43,7 @@ sys.path.insert(0, ROOT)
 M_ROWS = 5000 * 65
 WIDTH = 384
 FAN_IN = 384
+TRAFFIC_FILE = 'r2_xty_traffic.json'  # written by tools/pmc_kernel.py from the PMC passes of this round's kernel
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
@@ -75,6 +77,10 @@ def level_front(ops, lv, dist=None):
                         out=unpack_gram(buf, n0, n1))
     # ordinary stream-ordered collective on the front stream: RCCL runs it on its own stream and the front
     # stream waits for it, so it overlaps with the back half of the previous level on the other stream
+    if lv.get('host_sync_before_collective'):
+        # gloo rehearsal only (two ranks time-slicing one GPU): gloo's device path waits for the tensor on its own
+        # side stream, which stalled behind the peer's queued kernels; a host sync first keeps it to plain copies
+        torch.cuda.synchronize()
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return G, na, nb, buf, None
 
@@ -157,8 +163,12 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ['NIF_BENCH_WATCHDOG']), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', choices=['c2', 'c1', 'c3', 'c4'], default='c2',
+                    help='c2 (default): the per-level throughput benchmark; c1 / c3 / c4: end-to-end fusion wall-clock of '
+                         'BASELINE.json configs 1 / 3 / 4 on one GPU (bench_e2e.py)')
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 200 levels; 5 fusions for c1/c3/c4)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps (default 10; 1 for c1/c3/c4)')
+    ap.add_argument('--hard-steps', type=int, default=20, help='timed levels of the hard-assignment variant (N = 1)')
     ap.add_argument('--rows', type=int, default=M_ROWS)
     ap.add_argument('--width', type=int, default=WIDTH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -166,6 +176,7 @@ def main():
                     help='matrix path of the Gram kernel: exact f32 MFMA (default, the parity path) or six bf16 MFMAs '
                          'on the exact three-way bf16 split of every operand (f32-level accuracy, different last bits)')
     ap.add_argument('--no-overlap', action='store_true', help='serial loop on one stream')
+    ap.add_argument('--no-kernel-timing', action='store_true', help='do not record HIP events around the Gram kernel')
     ap.add_argument('--overlap-multi', action='store_true', help='use the two-stream pipeline with N > 1 as well')
     ap.add_argument('--backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only to rehearse '
                                                       'the N > 1 code path on a box with fewer GPUs than ranks)')
@@ -188,12 +199,24 @@ def main():
             dist.init_process_group(args.backend)
     from neuron_interpolation_model_fusion_amd import ops
 
+    if args.workload != 'c2':
+        if world != 1:
+            raise SystemExit('--workload c1/c3/c4 are single-GPU end-to-end runs (use the default workload for N > 1)')
+        import bench_e2e
+        steps = 5 if args.steps is None else args.steps
+        warmup = 1 if args.warmup is None else args.warmup
+        print(json.dumps(bench_e2e.run(args.workload, ops, device, steps, warmup)), flush=True)
+        return
+    args.steps = 200 if args.steps is None else args.steps
+    args.warmup = 10 if args.warmup is None else args.warmup
+
     n = args.width
     m_total = args.rows
     lo = m_total * rank // world
     hi = m_total * (rank + 1) // world
     lv = make_level(hi - lo, n, FAN_IN if n == WIDTH else n, device, seed=1000 + rank)
     lv['split_bf16'] = args.gram == 'split-bf16'
+    lv['host_sync_before_collective'] = world > 1 and args.backend != 'nccl'
 
     def sync():
         if dist is not None:
@@ -218,7 +241,8 @@ def main():
     out = run_levels(args.warmup)
     sync()
     ops.profile_collect(ops.PROF_XTY)
-    ops.profile_enable(True, slots=[ops.PROF_XTY])  # spans of the dominant kernel only: each costs dispatch gaps
+    if not args.no_kernel_timing:
+        ops.profile_enable(True, slots=[ops.PROF_XTY])  # spans of the dominant kernel only: each costs dispatch gaps
     t0 = time.perf_counter()
     out = run_levels(args.steps)
     sync()
@@ -230,18 +254,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Second figure (N = 1): the same level on a HARD assignment instance -- model k's activations are unrelated to the
+    # target's (what two independently initialised networks give), so the dual initialisation matches few rows and
+    # the single-workgroup augmenting kernel does the work.  The planted instance above solves in ~25 us.
+    hard = None
+    if world == 1 and args.hard_steps > 0:
+        lvh = dict(lv)
+        gh = torch.Generator(device=device).manual_seed(4242)
+        lvh['act_k'] = torch.randn(hi - lo, n, device=device, generator=gh)
+        for _ in range(2):
+            level_step(ops, lvh)
+        torch.cuda.synchronize()
+        ops.profile_collect(ops.PROF_LAP)
+        ops.profile_enable(True, slots=[ops.PROF_LAP])
+        th = time.perf_counter()
+        for _ in range(args.hard_steps):
+            level_step(ops, lvh)
+        torch.cuda.synchronize()
+        th = time.perf_counter() - th
+        ops.profile_enable(False)
+        lap_ms, lap_n = ops.profile_collect(ops.PROF_LAP)
+        hard = {'levels_per_s': args.hard_steps / th, 'ms_per_step': th / args.hard_steps * 1e3, 'steps': args.hard_steps,
+                'lap_kernel_ms': lap_ms / max(lap_n, 1),
+                'instance': 'act_k ~ N(0,1) independent of act_f (no planted matching), serial loop'}
+        del lvh
+
     # sanity: the planted permutation is recovered (N = 1: exactly this rank's data; N > 1: summed Gram)
     col = out[0].long()
     recovered = bool((col == lv['perm']).all())  # model-k neuron i is target neuron perm[i] plus noise
 
     result = None
     lv.pop('split_bf16')
+    lv.pop('host_sync_before_collective')
     if rank == 0:
         # HBM bytes per launch of the dominant kernel from the last committed PMC passes (separate
         # rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled as the microarch guide prescribes)
         traffic = None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r1_b_xty_traffic.json')) as fh:
+            with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as fh:
                 rec = json.load(fh)
             if rec.get('shape') == f'm={hi - lo},n={n},f32' and args.gram == 'f32':
                 traffic = rec['hbm_bytes_per_launch']
@@ -272,7 +322,9 @@ def main():
                 'rows_per_gpu': hi - lo,
                 'parallelism': f'rows sharded over {world} GPU(s), one f64 all-reduce of [G|na|nb] per level'
                                if world > 1 else 'single GPU',
+                'lap_instance': 'planted (noisy column permutation: the dual initialisation matches nearly every row)',
                 'planted_permutation_recovered': recovered,
+                'hard_instance': hard,
                 'overlap': 'two-stream software pipeline over levels' if overlap else 'serial',
             },
             'roofline': {
@@ -284,7 +336,8 @@ def main():
                 'unit': 'TFLOP/s',
                 'frac': (achieved / peak) if achieved else None,
                 'traffic': traffic,
-                'traffic_unit': 'bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_b_xty_traffic.json)',
+                'traffic_unit': f'bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of '
+                                f'this command, profiles/{TRAFFIC_FILE})',
                 'algorithmic_bytes_per_launch': 2.0 * (hi - lo) * n * 4,
                 'avg_kernel_ms': avg_ms,
                 'launches': launches,

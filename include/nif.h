@@ -67,8 +67,13 @@ int nif_device_count(void);
 #define NIF_PROF_XTY 0
 #define NIF_PROF_LAP 1
 #define NIF_PROF_KMEANS 2
+#define NIF_PROF_EIGH_TRD 3 /* all tridiagonalisation passes of one nif_eigh_kept_f64 call (one span per call) */
 void nif_profile_enable(int on); /* bit s set: record spans of slot s; negative: every slot; 0: off */
 int nif_profile_collect(int slot, double* total_ms, int64_t* launches);
+/* Algorithmic work the entry points booked for the recorded spans of a slot since the last call (then cleared).
+ * NIF_PROF_EIGH_TRD: bytes of the fused update + matrix-vector passes, 16 (n - j - 1)^2 per column j (each element of
+ * the trailing matrix read once and written once).  The other slots book nothing: their callers know the shapes. */
+int nif_profile_work(int slot, double* units);
 
 /* ---------------------------------------------------------------------------
  * nif_xty: G = A^T B summed over the m sample rows, plus the squared column

@@ -39,6 +39,7 @@ SIGNATURES = {
     'nif_device_count': (_i32, []),
     'nif_profile_enable': (None, [_i32]),
     'nif_profile_collect': (_i32, [_i32, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
+    'nif_profile_work': (_i32, [_i32, _c.POINTER(_c.c_double)]),
     'nif_xty_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32]),
     'nif_xty': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     'nif_cost_dist': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),

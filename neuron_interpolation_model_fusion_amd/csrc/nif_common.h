@@ -103,6 +103,7 @@ static inline int launch_ok() {
 // around the dominant kernel of an entry point.  No-ops unless enabled.
 void prof_begin(int slot, hipStream_t st);
 void prof_end(int slot, hipStream_t st);
+void prof_add_work(int slot, double units);  // algorithmic work of the spans of a slot (nif_profile_work)
 
 }  // namespace nif
 

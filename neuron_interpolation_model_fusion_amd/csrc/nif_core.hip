@@ -39,6 +39,7 @@ std::mutex g_mu;
 unsigned g_enabled = 0;  // bit s: spans of slot s are recorded
 std::vector<Span> g_spans;
 hipEvent_t g_open[NIF_PROFILE_SLOTS];
+double g_work[NIF_PROFILE_SLOTS];
 }  // namespace
 
 void prof_begin(int slot, hipStream_t st) {
@@ -60,6 +61,22 @@ void prof_end(int slot, hipStream_t st) {
   g_open[slot] = nullptr;
 }
 }  // namespace nif
+
+namespace nif {
+void prof_add_work(int slot, double units) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (slot < 0 || slot >= NIF_PROFILE_SLOTS || !((g_enabled >> slot) & 1)) return;
+  g_work[slot] += units;
+}
+}  // namespace nif
+
+extern "C" int nif_profile_work(int slot, double* units) {
+  if (!units || slot < 0 || slot >= NIF_PROFILE_SLOTS) return NIF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(nif::g_mu);
+  *units = nif::g_work[slot];
+  nif::g_work[slot] = 0.0;
+  return NIF_OK;
+}
 
 extern "C" void nif_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(nif::g_mu);

@@ -822,8 +822,11 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
       (void)hipFuncSetAttribute((const void*)trd_step_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
+    prof_begin(NIF_PROF_EIGH_TRD, st);
+    double trd_bytes = 0.0;
     for (int j = 0; j + 2 < n; ++j) {
       t.j = j;
+      trd_bytes += 16.0 * (double)(n - j - 1) * (double)(n - j - 1);
       const int groups = (n - (j + 1) / TRD_ROWS * TRD_ROWS + TRD_ROWS - 1) / TRD_ROWS;  // row groups still alive
       int b8 = (groups + 7) / 8;   // one group of rows per workgroup when they all fit
       if (b8 > 32) b8 = 32;
@@ -839,6 +842,8 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
       else hipLaunchKernelGGL(trd_step_kernel<6>, grid, block, lds, st, t);
     }
     hipLaunchKernelGGL(trd_finish_kernel, dim3(1), dim3(64), 0, st, t);
+    prof_end(NIF_PROF_EIGH_TRD, st);
+    prof_add_work(NIF_PROF_EIGH_TRD, trd_bytes);
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
 

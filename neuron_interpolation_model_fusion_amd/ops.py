@@ -228,7 +228,7 @@ def refit_gather(W0, W1, rowsrc=None, colsrc=None, alpha=1.0, beta=1.0, sp=1):
     return out.reshape(shape)
 
 
-PROF_XTY, PROF_LAP, PROF_KMEANS = 0, 1, 2
+PROF_XTY, PROF_LAP, PROF_KMEANS, PROF_EIGH_TRD = 0, 1, 2, 3
 
 
 def profile_enable(on=True, slots=None):
@@ -243,6 +243,13 @@ def profile_collect(slot):
     ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
     check(lib.nif_profile_collect(slot, ctypes.byref(ms), ctypes.byref(cnt)), 'nif_profile_collect')
     return ms.value, cnt.value
+
+
+def profile_work(slot):
+    """Algorithmic work booked for a slot's spans since the last call (bytes for PROF_EIGH_TRD)."""
+    w = ctypes.c_double(0.0)
+    check(lib.nif_profile_work(slot, ctypes.byref(w)), 'nif_profile_work')
+    return w.value
 
 
 # ---- least-squares refit (hf_kf.py:213,233-234,377,397) ---------------------------------------------
