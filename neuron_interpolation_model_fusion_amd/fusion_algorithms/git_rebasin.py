@@ -56,8 +56,8 @@ class GitRebasin:
         G, na, nb = ops.xty(acts0, acts1)
         return ops.cost_dist(G, na, nb, s0, s1).cpu()
 
-    def _match_layer(self, layer, num_layers, device):
-        """col_ind of the min-cost matching of model1's neurons to model0's (git_rebasin.py:80-123)."""
+    def _layer_cost(self, layer, device):
+        """Cost matrix of one layer (git_rebasin.py:92-109) from the activations captured once of both ORIGINAL models."""
         pre0 = self._rows(self.model0.get_inputs_and_preactivations(layer)[1]).to(device)
         pre1 = self._rows(self.model1.get_inputs_and_preactivations(layer)[1]).to(device)
         s0 = self.neuron_importance_scores0[layer].to(device)
@@ -66,10 +66,18 @@ class GitRebasin:
         cost = ops.cost_dist(G, na, nb, s0, s1)
         if self.cost_matrices is not None:
             self.cost_matrices.append(cost)
-        col = ops.lap_solve(cost, scipy_order=True)  # scipy's matching also under exact ties (dead ReLU units)
-        if layer == num_layers - 1:
-            col = torch.arange(cost.shape[0], device=device, dtype=torch.int32)  # identity on the output layer
-        return col
+        return cost
+
+    def _match_all_layers(self, num_layers, device):
+        """col_ind of every layer's min-cost matching of model1's neurons to model0's (git_rebasin.py:80-123).  The
+        reference solves them inside its layer loop, but no layer's cost depends on another layer's matching (the
+        activations are those of the un-fused models), so all costs are built first and the assignment problems --
+        one workgroup each -- are solved side by side (ops.lap_solve_many), in scipy's order under exact ties."""
+        costs = [self._layer_cost(layer, device) for layer in range(num_layers)]
+        cols = ops.lap_solve_many(costs, scipy_order=True)
+        n_last = costs[-1].shape[0]
+        cols[-1] = torch.arange(n_last, device=device, dtype=torch.int32)  # identity on the output layer (:115-116)
+        return cols
 
     def fuse(self, activations_dataset, activations_labels, neuron_importance_method, handle_skip=False):
         if neuron_importance_method not in self.neuron_importance_methods:
@@ -81,6 +89,7 @@ class GitRebasin:
             fused_hat = self.model0.copy_model().eval()
         self.permutations = []
 
+        cols = self._match_all_layers(num_layers, device)
         prev_is_conv, prev_col = False, None
         skip_col, residual_col, residual_idx = None, None, None
         for layer in range(num_layers):
@@ -91,7 +100,7 @@ class GitRebasin:
             b1 = self.model1.get_ordered_trainable_named_layers[layer].layer.bias
             s0 = self.neuron_importance_scores0[layer].to(device)
             s1 = self.neuron_importance_scores1[layer].to(device)
-            col = self._match_layer(layer, num_layers, device)
+            col = cols[layer]
 
             in_col = prev_col
             if layer > 0 and is_conv and handle_skip:

@@ -152,6 +152,28 @@ class OTFusion:
         # plans of the previous layer per model, as (row4col, None) -- row4col[j'] = model-k unit transported
         # to fused unit j' -- or (None, SparsePlan); (None, None) = the identity coupling diag(nu_prev) of the
         # input (otfusion.py:216-217)
+        # Activation mode: the ground metric of (layer, model) comes from activations captured once, so no plan depends
+        # on another one.  The assignment-shaped problems (uniform marginals, equal widths) are solved up front, side
+        # by side on their own streams (one workgroup each); the rest go through _solve_plan in the loop.
+        presolved = {}
+        if mode == 'acts':
+            keys, costs = [], []
+            for layer in range(num_layers):
+                n_f = get_layer_width(fused_hat, layer)
+                for k, model in enumerate(self.models):
+                    n_k = get_layer_width(model, layer)
+                    if n_k != n_f:
+                        continue
+                    if use_scores:
+                        mu_, nu_ = self.neuron_importance_scores[k][layer], self.target_neuron_importance_scores[layer]
+                        if not (bool(torch.equal(mu_, mu_[:1].expand_as(mu_))) and
+                                bool(torch.equal(nu_, nu_[:1].expand_as(nu_)))):
+                            continue
+                    keys.append((layer, k))
+                    costs.append(self._get_ground_metric(model, fused_hat, layer, None))
+            if costs:
+                _, rows_ = ops.lap_solve_many(costs, scipy_order=False, rows=True)
+                presolved = {key: (C, r) for key, C, r in zip(keys, costs, rows_)}
         prev_plan = [(None, None) for _ in self.models]
         prev_width = [input_dim for _ in self.models]
         nu_prev = None
@@ -200,7 +222,9 @@ class OTFusion:
                 cols = p_sparse.scaled(col_scale=1.0 / nu_prev) if p_sparse is not None else None
 
                 # ground metric; 'wts' mode needs the edge-aligned weight W_k T_prev diag(1/nu_prev) first
-                if mode == 'acts':
+                if (layer, k) in presolved:
+                    C = presolved[(layer, k)][0]
+                elif mode == 'acts':
                     C = self._get_ground_metric(model, fused_hat, layer, None)
                 else:
                     if cols is None:
@@ -208,7 +232,7 @@ class OTFusion:
                     else:
                         edges = ops.refit_sparse(None, wk_flat, cols=cols, sp=sp)
                     C = self._get_ground_metric(model, fused_hat, layer, edges)
-                perm, sparse = _solve_plan(C, mu, nu)
+                perm, sparse = (presolved[(layer, k)][1], None) if (layer, k) in presolved else _solve_plan(C, mu, nu)
                 self.plans.append((layer, k, perm if sparse is None else sparse))
                 last = layer == num_layers - 1  # T_corrected = I on the output layer (otfusion.py:315-316)
                 if handle_bias:

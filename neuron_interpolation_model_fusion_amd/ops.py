@@ -201,6 +201,101 @@ def lap_solve(C, duals=False, scipy_order=False):
     return col
 
 
+def lap_solve_many(costs, scipy_order=True, rows=False):
+    """``lap_solve(C, scipy_order=scipy_order)`` for several independent square f32 cost matrices at once (the layers of
+    Git Re-Basin / OTFusion in activation mode: their costs come from activations captured once, so nothing orders the
+    assignments).  The augmenting kernel is ONE workgroup per problem, so the problems run side by side on their own
+    HIP streams, and the host decisions of the scipy-order path (nearly solved? certificate clean?) are read back once
+    per stage for all problems instead of once per problem.  Returns the list of col4row vectors (with rows=True:
+    (col4row list, row4col list)); ``last_paths`` names the path each problem took."""
+    for C in costs:
+        _need_gpu(C)
+        if C.dtype != torch.float32 or C.dim() != 2 or C.shape[0] != C.shape[1]:
+            raise TypeError('lap_solve_many needs square float32 matrices')
+        if C.shape[0] > _lib.NIF_LAP_MAX_N:
+            raise _lib.NifError(f'lap_solve_many: n={C.shape[0]} exceeds NIF_LAP_MAX_N={_lib.NIF_LAP_MAX_N}')
+    if not costs:
+        return ([], []) if rows else []
+    costs = [_mat(C, 'C') for C in costs]
+    dev = costs[0].device
+    with torch.cuda.device(dev):
+        if scipy_order:
+            bad = torch.stack([(torch.isnan(C) | (C == float('-inf'))).any() for C in costs])
+            if bool(bad.any()):
+                raise ValueError('matrix contains invalid numeric entries')
+        main = torch.cuda.current_stream(dev)
+        P = []
+        for C in costs:
+            n = C.shape[0]
+            nbytes = lib.nif_lap_workspace_bytes(n)
+            st = torch.cuda.Stream(dev)
+            st.wait_stream(main)
+            P.append(dict(C=C, n=n, nbytes=nbytes, stream=st,
+                          col=torch.empty(n, dtype=torch.int32, device=dev), row=torch.empty(n, dtype=torch.int32, device=dev),
+                          u=torch.empty(n, dtype=torch.float64, device=dev), v=torch.empty(n, dtype=torch.float64, device=dev),
+                          ws=torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev), path='fast'))
+
+        def run(p, flags):
+            with torch.cuda.stream(p['stream']):
+                check(lib.nif_lap_solve_f32(_ptr(p['C']), _ld(p['C']), p['n'], flags, _ptr(p['col']), _ptr(p['row']),
+                                            _ptr(p['u']), _ptr(p['v']), _ptr(p['ws']), p['nbytes'],
+                                            ctypes.c_void_p(p['stream'].cuda_stream)), 'nif_lap_solve_f32')
+
+        def join():
+            for p in P:
+                main.wait_stream(p['stream'])
+
+        if not scipy_order:
+            for p in P:
+                run(p, 0)
+        else:
+            for p in P:
+                p['staged'] = scipy_order is True and p['n'] >= 32
+            staged = [p for p in P if p['staged']]
+            for p in P:
+                p['path'] = 'replay'
+                if p['staged']:
+                    run(p, _lib.NIF_LAP_INIT_ONLY)
+                else:
+                    run(p, _lib.NIF_LAP_SCIPY_ORDER)
+            if staged:
+                join()
+                free = torch.stack([(p['col'] < 0).sum() for p in staged]).tolist()   # one read-back for all
+                certs = []
+                for p, f in zip(staged, free):
+                    if f * 8 <= p['n']:  # nearly solved by the dual initialisation: finish under a step budget, certify
+                        run(p, _lib.NIF_LAP_RESUME | ((16 * f + 64) << _lib.NIF_LAP_BUDGET_SHIFT))
+                        with torch.cuda.stream(p['stream']):
+                            p['cnt'] = torch.empty(1, dtype=torch.int32, device=dev)
+                            check(lib.nif_lap_count_tight_f32(_ptr(p['C']), _ld(p['C']), p['n'], _ptr(p['col']), _ptr(p['u']),
+                                                              _ptr(p['v']), LAP_CERT_TOL, _ptr(p['cnt']),
+                                                              ctypes.c_void_p(p['stream'].cuda_stream)),
+                                  'nif_lap_count_tight_f32')
+                        certs.append(p)
+                    else:
+                        run(p, _lib.NIF_LAP_SCIPY_ORDER)
+                if certs:
+                    join()
+                    for p, c in zip(certs, torch.cat([p['cnt'] for p in certs]).tolist()):
+                        if c == 0:
+                            p['path'] = 'certified'
+                        else:
+                            run(p, _lib.NIF_LAP_SCIPY_ORDER)
+        join()
+        for p in P:  # the per-problem buffers were used on side streams
+            for t in (p['col'], p['row'], p['u'], p['v'], p['ws']):
+                t.record_stream(p['stream'])
+        if scipy_order:
+            infeasible = torch.stack([(p['col'] < 0).any() for p in P if p['path'] == 'replay'] or
+                                     [torch.zeros((), dtype=torch.bool, device=dev)])
+            if bool(infeasible.any()):
+                raise ValueError('cost matrix is infeasible')
+    lap_solve_many.last_paths = [p['path'] for p in P]
+    if rows:
+        return [p['col'] for p in P], [p['row'] for p in P]
+    return [p['col'] for p in P]
+
+
 def refit_gather(W0, W1, rowsrc=None, colsrc=None, alpha=1.0, beta=1.0, sp=1):
     """out[i, c*sp+e] = a_i W0[i, c*sp+e] + b_i W1[rowsrc[i], colsrc[c]*sp+e] (see nif_refit_gather).
 

@@ -703,3 +703,36 @@ def test_ls_solve_with_own_eigensolver_matches_f64_pinv(ops, m, d):
     assert sol['rank'] == int((s > rtol * s[0]).sum())
     W = sol['W'].cpu().numpy()
     assert np.abs(W - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_lap_solve_many_equals_one_by_one(ops):
+    """Concurrent multi-stream solves of independent problems: same matchings and paths as solving them in turn, in the
+    fast mode and in scipy order (a planted instance takes the certified path, a tie-laden one the replay kernel)."""
+    g = torch.Generator().manual_seed(21)
+    costs = []
+    for n in (40, 384, 129, 16):
+        costs.append(torch.rand(n, n, generator=g).cuda())
+    A = torch.randn(500, 200, generator=g)
+    perm = torch.randperm(200, generator=g)
+    B = A[:, perm] + 0.05 * torch.randn(500, 200, generator=g)
+    G, na, nb = ops.xty(A.cuda(), B.cuda())
+    costs.append(ops.cost_dist(G, na, nb))                      # nearly solved by the dual initialisation
+    tied = torch.rand(96, 96, generator=g)
+    tied[:, 48:] = tied[:, :48]                                 # duplicated columns: exact ties
+    costs.append(tied.cuda())
+    for mode in (False, True):
+        one = [ops.lap_solve(C, scipy_order=mode) for C in costs]
+        paths = []
+        for C in costs:
+            ops.lap_solve(C, scipy_order=mode)
+            paths.append(ops.lap_solve.last_path)
+        many, rows = ops.lap_solve_many(costs, scipy_order=mode, rows=True)
+        for a, b, r in zip(one, many, rows):
+            assert torch.equal(a, b)
+            assert torch.equal(r[b.long()].long(), torch.arange(b.shape[0], device='cuda'))
+        assert ops.lap_solve_many.last_paths == paths
+    if True:
+        from scipy.optimize import linear_sum_assignment
+        many = ops.lap_solve_many(costs, scipy_order=True)
+        for C, col in zip(costs, many):
+            assert (linear_sum_assignment(C.cpu().numpy())[1] == col.cpu().numpy()).all()
