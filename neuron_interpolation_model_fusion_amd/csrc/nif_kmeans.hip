@@ -17,6 +17,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/nif.h"
 #include "nif_common.h"
 
@@ -139,6 +141,130 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const do
   for (int q = 0; q < EPT; ++q) {
     const int j = threadIdx.x + q * 1024;
     if (j < N) {
+      mind[j] = md[q];
+      assign[j] = lab[q];
+    }
+  }
+}
+
+// ---- the same initialisation spread over several workgroups (N > 4096) ------------------------------------------
+// Workgroup b owns the neurons [b * span, (b + 1) * span) -- running minimum distance, |y_j|^2 and label in registers
+// -- and streams only its slice of the picked Gram row.  One exchange per pick: every workgroup posts its local
+// (maximum, index) as three self-tagged 8-byte granules {tag = pick + 1, 32 payload bits} (value high word, low word,
+// index; one agent-scope store each, so a granule is never torn), wave 0 of every workgroup sweeps all 3 * B granules
+// with agent-scope loads until every tag shows the current pick, and each workgroup reduces them the same way
+// (larger value, lower index on ties), so all continue with the same pick.  Slots are double-buffered by pick parity:
+// a workgroup can be at most one pick ahead of the slowest reader.  The mailbox is zeroed by the launch function
+// before every call; spins are bounded (a timeout marks the remaining picks -1 and every workgroup leaves).
+constexpr int FI_MAX_WG = 16;
+constexpr int FI_GRANULES = 2 * FI_MAX_WG * 3;          // per call region: [parity][workgroup][hi, lo, idx]
+constexpr int FI_REGION_WORDS = FI_GRANULES + 32;       // + timeout word, padded: 128 x 8 bytes = 1 KiB
+constexpr int FI_REGIONS = 64;                          // calls in flight at once (each takes the next region)
+static __device__ __align__(256) unsigned long long fi_mailbox[FI_REGIONS * FI_REGION_WORDS];
+
+template <int EPT>
+__global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const double* __restrict__ G, int64_t ldg,
+                                                                          const double* __restrict__ nn, int N, int k,
+                                                                          int first, int span, int* __restrict__ picks,
+                                                                          int* __restrict__ assign,
+                                                                          double* __restrict__ mind,
+                                                                          unsigned long long* mbox) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  __shared__ double sv[16];
+  __shared__ int sj[16];
+  __shared__ int s_next;
+  const int B = gridDim.x, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int j0 = b * span;
+  double md[EPT], nj[EPT];
+  int lab[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int j = j0 + tid + q * 1024;
+    nj[q] = (tid + q * 1024 < span && j < N) ? nn[j] : 0.0;
+    md[q] = 0.0;
+    lab[q] = 0;
+  }
+  gu64* box = (gu64*)mbox;
+  gu64* tmo = box + FI_GRANULES;
+  int idx = first;
+  int c = 0;
+  for (; c < k; ++c) {
+    if (b == 0 && tid == 0) picks[c] = idx;
+    const double* __restrict__ row = G + (int64_t)idx * ldg;
+    const double gii = row[idx];
+    double bv = -INFINITY;
+    int bj = INT_MAX;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int j = j0 + tid + q * 1024;
+      if (tid + q * 1024 < span && j < N) {
+        double d2 = gii - 2.0 * row[j] + nj[q];
+        if (!(d2 > 0.0)) d2 = 0.0;
+        const double d = sqrt(d2);
+        if (c == 0 || d < md[q]) {
+          md[q] = d;
+          lab[q] = c;
+        }
+        if (md[q] > bv) {  // j ascends within a thread: strict > keeps the lowest index
+          bv = md[q];
+          bj = j;
+        }
+      }
+    }
+    if (c + 1 == k) break;  // nothing left to pick
+    block_argmax(bv, bj, sv, sj);
+    const unsigned epoch = (unsigned)c + 1u;
+    gu64* slots = box + (c & 1) * (FI_MAX_WG * 3);
+    if (tid == 0) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(bv);
+      const unsigned long long tag = (unsigned long long)epoch << 32;
+      __hip_atomic_store(slots + b * 3 + 0, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(slots + b * 3 + 1, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(slots + b * 3 + 2, tag | (unsigned)bj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 64) {  // wave 0 sweeps every workgroup's granules
+      const int ng = 3 * B;
+      unsigned val = 0;
+      bool ok = false, failed = false;
+      for (unsigned spins = 0;; ++spins) {
+        if (lane < ng) {
+          const unsigned long long x = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          val = (unsigned)x;
+          ok = (unsigned)(x >> 32) == epoch;
+        } else {
+          ok = true;
+        }
+        if (__all(ok)) break;
+        if (spins > (1u << 22) ||
+            (spins % 64 == 63 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          failed = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      int nxt = -1;
+      if (!failed) {
+        const int src = lane < B ? 3 * lane : 0;
+        const unsigned hi = (unsigned)__shfl((int)val, src, 64), lo = (unsigned)__shfl((int)val, src + 1, 64);
+        const int oj = __shfl((int)val, src + 2, 64);
+        double v = lane < B ? __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)) : -INFINITY;
+        const double wmax = -wave_min_f64(-v);
+        nxt = (int)wave_min_u32((lane < B && v == wmax) ? (unsigned)oj : 0xffffffffu);
+      } else if (lane == 0) {
+        __hip_atomic_store(tmo, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) s_next = nxt;
+    }
+    __syncthreads();
+    idx = s_next;
+    if (idx < 0) break;  // timed out: uniform over the workgroup
+  }
+  if (idx < 0 && b == 0)
+    for (int cc = c + 1 + tid; cc < k; cc += 1024) picks[cc] = -1;
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int j = j0 + tid + q * 1024;
+    if (tid + q * 1024 < span && j < N) {
       mind[j] = md[q];
       assign[j] = lab[q];
     }
@@ -536,6 +662,38 @@ extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const doub
     return NIF_ERR_INVALID_ARG;
   nif::clear_err();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const int fi_single = nif::env_int("NIF_KMEANS_INIT_SINGLE_WG");  // tuning aid: keep the one-workgroup kernel
+  if (N > 4096 && N <= nif::FI_MAX_WG * 4096 && !fi_single) {
+    // several workgroups, one mailbox exchange per pick (see kmeans_farthest_init_multi_kernel)
+    static std::mutex mu;
+    static unsigned long long* base[64];
+    static unsigned seq = 0;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NIF_ERR_NO_DEVICE;
+    unsigned long long* region;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!base[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(nif::fi_mailbox)) != hipSuccess || !p) return NIF_ERR_NO_DEVICE;
+        base[dev] = reinterpret_cast<unsigned long long*>(p);
+      }
+      region = base[dev] + (size_t)(seq++ % nif::FI_REGIONS) * nif::FI_REGION_WORDS;
+    }
+    int B = (N + 2047) / 2048;            // two neurons per lane where that fills <= 16 workgroups
+    if (B > nif::FI_MAX_WG) B = nif::FI_MAX_WG;
+    const int span = (N + B - 1) / B;
+    const int ept = (span + 1023) / 1024;
+    if (hipMemsetAsync(region, 0, nif::FI_REGION_WORDS * sizeof(unsigned long long), st) != hipSuccess) return NIF_ERR_LAUNCH;
+#define NIF_FIM_GO(E)                                                                                                \
+  hipLaunchKernelGGL(nif::kmeans_farthest_init_multi_kernel<E>, dim3(B), dim3(1024), 0, st, G, ldg, nn, N, k, first, span, \
+                     picks, assign, mind, region)
+    if (ept <= 1) NIF_FIM_GO(1);
+    else if (ept <= 2) NIF_FIM_GO(2);
+    else NIF_FIM_GO(4);
+#undef NIF_FIM_GO
+    return nif::launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+  }
   const int ept = (N + 1023) / 1024;
 #define NIF_FI_GO(E) \
   hipLaunchKernelGGL(nif::kmeans_farthest_init_reg_kernel<E>, dim3(1), dim3(1024), 0, st, G, ldg, nn, N, k, first, picks, \

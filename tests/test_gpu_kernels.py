@@ -466,7 +466,7 @@ def test_kmeans_targets_all_staging_variants(ops, N, k, m):
     assert float(T[:, kprime:].abs().max()) == 0.0 if kprime < k else True
 
 
-@pytest.mark.parametrize('N,k', [(64, 5), (300, 20), (3000, 33), (40000, 6)])
+@pytest.mark.parametrize('N,k', [(64, 5), (300, 20), (3000, 33), (4097, 12), (6000, 40), (24576, 70), (40000, 6), (65536, 5), (70000, 4)])
 def test_kmeans_farthest_init_matches_sequential_reference(ops, N, k):
     g = torch.Generator().manual_seed(N)
     A = torch.randn(24, N, generator=g).double()
