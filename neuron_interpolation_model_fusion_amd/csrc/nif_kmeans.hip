@@ -615,8 +615,255 @@ __global__ void kmeans_targets_lds_kernel(const float* __restrict__ A, int64_t l
   }
 }
 
+// The wide-load version.  What bounds the kernel above is not HBM but the CU's vector-memory pipe: every (row,
+// cluster) pair re-reads seg / compact / S and chases order[t] -> w[i] through scattered 4-byte global loads, and the
+// loads of the next tile only start after the walk.  Here
+//   * a row is staged in LDS in CLUSTER-SORTED order (element i goes to position pos[i], its place in `order`; the
+//     positions of the elements a lane stages are the same for every tile and live in registers), bank-swizzled so
+//     lanes that walk neighbouring clusters do not collide;
+//   * a lane owns CLUSTERS, not pairs: its clusters' segment, output column and weight total are read once, and it
+//     walks its clusters in every row of the tile it is assigned;
+//   * the weights sit in LDS next to the tile, in the same sorted, swizzled order, as far as the CU's 160 KB allow
+//     (WL sorted positions).  Clusters that reach past WL (only wide levels have any) keep their first four weights
+//     in registers and take the rest from the member-major table wT[t * k + c] (coalesced across a wave);
+//   * the NEXT tile is fetched into registers (PF float4 per lane) as soon as no other global load can follow: after
+//     the clusters that read wT, before the ones that live in LDS (the memory counter retires in order: a later wT
+//     load would make the walk wait for the whole prefetch).  Every load and LDS read is unconditional (clamped
+//     address + select), so nothing serialises behind a branch.
+// Same members in the same order with the same f64 arithmetic: same bits as above.  Columns >= *kprime are zeroed here.
+// Requires N % 4 == 0, lda % 4 == 0, A 16-byte aligned, R * N / 4 <= PF * blockDim.x, k <= CPT * blockDim.x,
+// R * N < 65536, R * lda < 2^31; LDS holds R * N floats rounded up to 64, then WL floats (WL % 64 == 0).
+__global__ void kmeans_sorted_kernel(const int* __restrict__ order, const int* __restrict__ assign,
+                                     const int* __restrict__ seg, const float* __restrict__ w, int N, int k,
+                                     int* __restrict__ pos, float* __restrict__ wsorted, float* __restrict__ wT) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const int i = order[t];
+  const int c = assign[i];
+  const float wi = w[i];
+  pos[i] = t;
+  wsorted[t] = wi;
+  wT[(int64_t)(t - seg[c]) * k + c] = wi;
+}
+
+__device__ __forceinline__ int km_sw(int a) { return a ^ ((a >> 6) & 63); }
+
+template <int PF, int CPT>
+__global__ __launch_bounds__(1024) void kmeans_targets_sw_kernel(
+    const float* __restrict__ A, int64_t lda, int64_t m, const float* __restrict__ wsorted,
+    const float* __restrict__ wT, const int* __restrict__ pos, const int* __restrict__ seg,
+    const int* __restrict__ compact, const double* __restrict__ S, const int* __restrict__ kprime, int N, int k, int R,
+    int WL, float* __restrict__ T, int64_t ldt) {
+  extern __shared__ __attribute__((aligned(16))) float km_tile[];  // [R][N] sorted + swizzled rows, then WL weights
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  const int n4 = N >> 2;
+  const int kp = kprime[0];
+  float* __restrict__ wl = km_tile + ((R * N + 63) & ~63);
+  for (int p = tid; p < WL; p += nthreads) wl[km_sw(p)] = p < N ? wsorted[p] : 0.0f;
+  // per staging slot: the float4 in flight, its four LDS positions (16 bits each) and its element offset inside the
+  // tile's block of rows
+  float4 pf[PF];
+  unsigned pxy[PF], pzw[PF];
+  int foff[PF];
+#pragma unroll
+  for (int e = 0; e < PF; ++e) {
+    const int idx = tid + e * nthreads;
+    pxy[e] = pzw[e] = 0u;
+    foff[e] = -1;
+    if (idx < R * n4) {
+      const int rr = idx / n4, q = idx - rr * n4;
+      const int4 pq = reinterpret_cast<const int4*>(pos)[q];
+      pxy[e] = (unsigned)km_sw(rr * N + pq.x) | ((unsigned)km_sw(rr * N + pq.y) << 16);
+      pzw[e] = (unsigned)km_sw(rr * N + pq.z) | ((unsigned)km_sw(rr * N + pq.w) << 16);
+      foff[e] = rr * (int)lda + 4 * q;
+    }
+  }
+  const int full_lim = (R - 1) * (int)lda + N;  // element offsets below rows * lda belong to rows of a ragged last tile
+  auto fetch = [&](int64_t r0) {
+    const int rows = (int)((m - r0) < R ? (m - r0) : R);
+    const int lim = rows == R ? full_lim : (rows - 1) * (int)lda + N;
+    const float* __restrict__ base = A + r0 * lda;
+#pragma unroll
+    for (int e = 0; e < PF; ++e) {  // branch-free: a slot without an element re-reads the tile's first one
+      const int off = (foff[e] >= 0 && foff[e] < lim) ? foff[e] : 0;
+      pf[e] = *reinterpret_cast<const float4*>(base + off);
+    }
+  };
+  // cluster ownership: with k <= blockDim the workgroup splits into G groups of k lanes, group g takes rows g, g + G, ...
+  int G = 1, g = 0, cbase = tid;
+  if (CPT == 1) {
+    G = nthreads / k;
+    g = tid / k;
+    cbase = tid - g * k;
+  }
+  int ccc[CPT];
+  unsigned cseg[CPT];  // first member | member count << 16
+  double cS[CPT];
+  float wfar[8];       // the first eight weights of this lane's first far cluster
+  unsigned far = 0u;  // bit j: cluster j reaches past the weights held in LDS ("far")
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int c = cbase + j * nthreads;
+    ccc[j] = -1; cseg[j] = 0u; cS[j] = 1.0;
+    const bool mine = CPT == 1 ? g < G : c < k;
+    if (mine) {
+      const int cc = compact[c];
+      if (cc >= 0) {
+        const int t0 = seg[c], n = seg[c + 1] - t0;
+        ccc[j] = cc;
+        cseg[j] = (unsigned)t0 | ((unsigned)n << 16);
+        cS[j] = S[cc];
+        if (t0 + n > WL) far |= 1u << j;
+      }
+    }
+  }
+  const int jf = far ? __builtin_ctz(far) : 0;
+  {
+    unsigned sf = 0u;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) sf = j == jf ? cseg[j] : sf;
+    const int c = cbase + jf * nthreads, n = far ? (int)(sf >> 16) : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wfar[u] = u < n ? wT[(int64_t)u * k + c] : 0.0f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * R;
+  int64_t r0 = (int64_t)blockIdx.x * R;
+  if (r0 < m) fetch(r0);
+  for (; r0 < m; r0 += stride) {
+    const int rows = (int)((m - r0) < R ? (m - r0) : R);
+    {
+      const int lim = rows == R ? full_lim : (rows - 1) * (int)lda + N;
+#pragma unroll
+      for (int e = 0; e < PF; ++e) {
+        if (foff[e] >= 0 && foff[e] < lim) {
+          km_tile[pxy[e] & 0xffffu] = pf[e].x;
+          km_tile[pxy[e] >> 16] = pf[e].y;
+          km_tile[pzw[e] & 0xffffu] = pf[e].z;
+          km_tile[pzw[e] >> 16] = pf[e].w;
+        }
+      }
+    }
+    __syncthreads();
+    // absent members add an exact +0 in both walks (acc never holds -0: it starts at +0)
+    if (__syncthreads_or(far != 0u)) {
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        if (ccc[j] < 0 || !((far >> j) & 1u)) continue;
+        const int t0 = (int)(cseg[j] & 0xffffu), n = (int)(cseg[j] >> 16);
+        const int c = cbase + j * nthreads;
+        for (int rr = g; rr < rows; rr += G) {
+          const int base = rr * N + t0;
+          double acc = 0.0;
+          int t = 0;
+          if (j == jf) {
+            float aq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float v = km_tile[km_sw(base + (u < n ? u : 0))];
+              aq[u] = u < n ? v : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)wfar[u] * (double)aq[u];
+            t = 8;
+          }
+          for (; t < n; t += 4) {
+            float wq[4], aq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const bool in = t + u < n;
+              const int tu = in ? t + u : t;
+              const float wv = wT[(int64_t)tu * k + c];
+              const float v = km_tile[km_sw(base + tu)];
+              wq[u] = in ? wv : 0.0f;
+              aq[u] = in ? v : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (double)wq[u] * (double)aq[u];
+          }
+          T[(r0 + rr) * ldt + ccc[j]] = (float)(acc / cS[j]);
+        }
+      }
+    }
+    if (r0 + stride < m) fetch(r0 + stride);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      if (ccc[j] < 0 || ((far >> j) & 1u)) continue;
+      const int t0 = (int)(cseg[j] & 0xffffu), n = (int)(cseg[j] >> 16);
+      float w4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (CPT == 1) {  // narrow levels: the lane's one cluster serves several rows of the tile with the same weights
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float wv = wl[km_sw(t0 + (u < n ? u : 0))];
+          w4[u] = u < n ? wv : 0.0f;
+        }
+      }
+      for (int rr = g; rr < rows; rr += G) {
+        const int base = rr * N + t0;
+        double acc = 0.0;
+        if (CPT == 1) {
+          float aq[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float v = km_tile[km_sw(base + (u < n ? u : 0))];
+            aq[u] = u < n ? v : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += (double)w4[u] * (double)aq[u];
+        }
+        for (int t = CPT == 1 ? 4 : 0; t < n; t += 4) {
+          float wq[4], aq[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool in = t + u < n;
+            const int tu = in ? t + u : t;
+            const float wv = wl[km_sw(t0 + tu)];
+            const float v = km_tile[km_sw(base + tu)];
+            wq[u] = in ? wv : 0.0f;
+            aq[u] = in ? v : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += (double)wq[u] * (double)aq[u];
+        }
+        T[(r0 + rr) * ldt + ccc[j]] = (float)(acc / cS[j]);
+      }
+    }
+    const int nz = k - kp;  // columns of empty clusters stay zero (hf_kf.py:494-504 / alf.py:288-289 compaction)
+    for (int p = tid; p < rows * nz; p += nthreads) {
+      const int rr = p / nz, cz = p - rr * nz;
+      T[(r0 + rr) * ldt + kp + cz] = 0.0f;
+    }
+    __syncthreads();
+  }
+}
+
+constexpr size_t KM_LDS_BUDGET = 159 * 1024;  // of the CU's 160 KB
+
+template <int PF, int CPT>
+static bool km_launch_sw(int64_t blocks, hipStream_t st, const float* A, int64_t lda, int64_t m, const float* wsorted,
+                         const float* wT, const int* pos, const int* seg, const int* compact, const double* S,
+                         const int* kprime, int N, int k, int R, float* T, int64_t ldt) {
+  auto kern = kmeans_targets_sw_kernel<PF, CPT>;
+  const size_t tile = (((size_t)R * N + 63) / 64) * 64 * sizeof(float);
+  size_t wl = (((size_t)N + 63) / 64) * 64;
+  if (tile + wl * sizeof(float) > KM_LDS_BUDGET) wl = (KM_LDS_BUDGET - tile) / sizeof(float) / 64 * 64;
+  const size_t lds = tile + wl * sizeof(float);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int per_cu = 0;  // resident workgroups per CU walk the row tiles, each with its next tile in flight
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 1024, lds) != hipSuccess || per_cu < 1) return false;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    cus = 256;
+  int64_t pb = (int64_t)cus * per_cu;
+  if (pb > blocks) pb = blocks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)pb), dim3(1024), lds, st, A, lda, m, wsorted, wT, pos, seg, compact, S, kprime,
+                     N, k, R, (int)wl, T, ldt);
+  return true;
+}
+
 struct KmWs {
-  size_t off_rank, off_counts, off_seg, off_compact, off_order, off_H, off_S, off_cn, off_partial, total;
+  size_t off_rank, off_counts, off_seg, off_compact, off_order, off_H, off_S, off_cn, off_partial, off_pos, off_wsorted, total;
   int nblk;
 };
 static inline size_t ka(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -632,6 +879,8 @@ static KmWs km_ws(int N, int k) {
   w.off_S = o; o += ka((size_t)k * 8);
   w.off_cn = o; o += ka((size_t)k * 8);
   w.off_partial = o; o += ka((size_t)((N + 63) / 64) * 8);
+  w.off_pos = o; o += ka((size_t)N * 4);
+  w.off_wsorted = o; o += ka((size_t)N * 4);
   w.off_H = o; o += ka((size_t)k * N * 8);
   w.total = o;
   return w;
@@ -795,7 +1044,6 @@ extern "C" int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const 
   clear_err();
   unsigned char* b = reinterpret_cast<unsigned char*>(ws);
   km_group(assign, N, k, ww, b, kprime, st);
-  (void)hipMemset2DAsync(T, (size_t)ldt * sizeof(float), 0, (size_t)k * sizeof(float), (size_t)m, st);
   int* order = reinterpret_cast<int*>(b + ww.off_order);
   int* seg = reinterpret_cast<int*>(b + ww.off_seg);
   int* compact = reinterpret_cast<int*>(b + ww.off_compact);
@@ -814,10 +1062,33 @@ extern "C" int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const 
     hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w, order, seg, compact, k, S);
     int64_t blocks = (m + R - 1) / R;
     if (blocks > 4096) blocks = 4096;
+    const bool vec = (N % 4 == 0) && (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    static const int no_pipe = env_int("NIF_KMEANS_TARGETS_PLAIN");  // tuning aid: the simple kernel
+    const size_t slots = (size_t)R * (N / 4);
+    const int pf = slots <= 3 * 1024 ? 3 : slots <= 4 * 1024 ? 4 : slots <= 6 * 1024 ? 6 : slots <= 9 * 1024 ? 9 : 0;
+    const int cpt = k <= 1024 ? 1 : k <= 2048 ? 2 : k <= 3072 ? 3 : k <= 4096 ? 4 : 0;
+    if (vec && !no_pipe && pf && cpt && !(pf == 9 && cpt == 4) && (int64_t)R * lda < (int64_t)1 << 31 && (size_t)R * N < 65536) {
+      int* pos = reinterpret_cast<int*>(b + ww.off_pos);
+      float* wT = reinterpret_cast<float*>(b + ww.off_H);  // member-major weights: (largest cluster) x k floats <= k N 8 bytes
+      float* wsorted = reinterpret_cast<float*>(b + ww.off_wsorted);
+      hipLaunchKernelGGL(kmeans_sorted_kernel, dim3((N + 255) / 256), dim3(256), 0, st, order, assign, seg, w, N, k, pos,
+                         wsorted, wT);
+      bool ok = false;
+#define NIF_KM_SW(P, C)                                                                                            \
+  if (pf == P && cpt == C)                                                                                         \
+    ok = km_launch_sw<P, C>(blocks, st, A, lda, m, wsorted, wT, pos, seg, compact, S, kprime, N, k, R, T, ldt);
+      NIF_KM_SW(3, 1) NIF_KM_SW(3, 2) NIF_KM_SW(3, 3) NIF_KM_SW(3, 4) NIF_KM_SW(4, 1) NIF_KM_SW(4, 2) NIF_KM_SW(4, 3)
+      NIF_KM_SW(4, 4) NIF_KM_SW(6, 1) NIF_KM_SW(6, 2) NIF_KM_SW(6, 3) NIF_KM_SW(6, 4) NIF_KM_SW(9, 1) NIF_KM_SW(9, 2)
+      NIF_KM_SW(9, 3)
+#undef NIF_KM_SW
+      if (ok) return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+    }
+    (void)hipMemset2DAsync(T, (size_t)ldt * sizeof(float), 0, (size_t)k * sizeof(float), (size_t)m, st);
     hipLaunchKernelGGL(kmeans_targets_lds_kernel, dim3((unsigned)blocks), dim3(threads_l), lds, st, A, lda, m, w, order,
                        seg, compact, S, N, k, R, T, ldt);
     return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
   }
+  (void)hipMemset2DAsync(T, (size_t)ldt * sizeof(float), 0, (size_t)k * sizeof(float), (size_t)m, st);
   const int threads = k >= 256 ? 256 : (k + 63) / 64 * 64;
   int64_t gy = m < 16384 ? m : 16384;
   hipLaunchKernelGGL(kmeans_targets_kernel, dim3((k + threads - 1) / threads, (unsigned)gy), dim3(threads), 0, st, A,

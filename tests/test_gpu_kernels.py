@@ -466,6 +466,45 @@ def test_kmeans_targets_all_staging_variants(ops, N, k, m):
     assert float(T[:, kprime:].abs().max()) == 0.0 if kprime < k else True
 
 
+def _targets_sequential(A, s, assign, k):
+    """The reference's weighted centroid rows as the library defines their rounding: members in ascending neuron
+    order, f64 products (exact) added one by one, one f64 division, one rounding to f32."""
+    A64, s64 = A.double(), s.double()
+    labels = [c for c in range(k) if (assign == c).any()]
+    members = [torch.nonzero(assign == c).flatten() for c in labels]
+    acc = torch.zeros(A.shape[0], len(labels), dtype=torch.float64)
+    S = torch.zeros(len(labels), dtype=torch.float64)
+    for t in range(max(len(mb) for mb in members)):
+        cols = [j for j, mb in enumerate(members) if len(mb) > t]
+        idx = torch.stack([members[j][t] for j in cols])
+        acc[:, cols] = acc[:, cols] + A64[:, idx] * s64[idx]
+        S[cols] = S[cols] + s64[idx]
+    return (acc / S).float()
+
+
+@pytest.mark.parametrize('N,k,m', [
+    (768, 384, 37),      # C4 shape: 16 rows per tile, one cluster per lane, ragged last tile
+    (4096, 2048, 19),    # two clusters per lane
+    (8192, 4000, 7),     # four clusters per lane
+    (24576, 3072, 5),    # C5 shape: one 96 KB row per tile, weights only partly in LDS
+    (20000, 96, 9),      # clusters of ~200 members, some reaching past the LDS-held weights
+    (30000, 700, 3),     # 120 KB rows
+    (6144, 768, 11),
+    (772, 5000, 3),      # more labels than the wide-load kernel takes: the simple kernel
+])
+def test_kmeans_targets_bits_equal_sequential_f64_sums(ops, N, k, m):
+    """Every staging variant of nif_kmeans_targets must give the SAME bits: summation order and arithmetic are fixed."""
+    A, s, assign = _kmeans_problem(N, k, m, N + 7 * k, empty=(1, 5) if k > 8 else ())
+    if k > N:
+        assign = (assign % 60).int()
+    km = ops.KMeans(None, torch.zeros(N, dtype=torch.float64).cuda(), s.cuda(), k)
+    T, kp = km.targets(A.cuda(), assign.cuda())
+    want = _targets_sequential(A, s, assign, k)
+    assert int(kp) == want.shape[1]
+    assert torch.equal(T[:, :int(kp)].cpu(), want)
+    assert float(T[:, int(kp):].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('N,k', [(64, 5), (300, 20), (3000, 33), (4097, 12), (6000, 40), (24576, 70), (40000, 6), (65536, 5), (70000, 4)])
 def test_kmeans_farthest_init_matches_sequential_reference(ops, N, k):
     g = torch.Generator().manual_seed(N)
