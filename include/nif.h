@@ -200,6 +200,11 @@ int nif_refit_gather(const float* W0, const float* W1, const int32_t* rowsrc, co
  * are measured to (KF: G = (XW)^T (XW) and nn = |a_j|^2, hf_kf.py:425-441,454-456;
  * ALF: G = A^T A and nn = diag(G), alf.py:227,242-244).  s = importance weights (f32, N).
  * Labels are int32.  ws from nif_kmeans_workspace_bytes(N, k).
+ * The three entry points that stream G come in two storage types: f64 (the accumulator type of nif_xty) and,
+ * suffix _gf32, the same matrix rounded once to f32 -- half the bytes per Lloyd step; every product and sum is
+ * still formed in f64, and the diagonal is taken from gdiag (N f64, the unrounded G[j][j]) so that the distance of
+ * a neuron to a centroid made of that neuron alone still cancels exactly.  The reference itself measures these distances in f32 (torch.cdist, hf_kf.py:431,456 /
+ * alf.py:227,244); the labels of every reference golden are the same with either storage.
  * ------------------------------------------------------------------------- */
 size_t nif_kmeans_workspace_bytes(int N, int k);
 
@@ -209,10 +214,14 @@ size_t nif_kmeans_workspace_bytes(int N, int k);
  * One workgroup; replaces k full k x N x m cdist calls by k reads of one Gram row. */
 int nif_kmeans_farthest_init(const double* G, int64_t ldg, const double* nn, int N, int k, int first,
                              int32_t* picks, int32_t* assign, double* mind, void* stream);
+int nif_kmeans_farthest_init_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, int N, int k,
+                                  int first, int32_t* picks, int32_t* assign, double* mind, void* stream);
 
 /* ALF initial assignment, alf.py:221-229: centroids are neurons c0 .. c0+k-1. */
 int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn, int N, int k, int c0,
                                  int32_t* assign, void* stream);
+int nif_kmeans_assign_to_neurons_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, int N,
+                                      int k, int c0, int32_t* assign, void* stream);
 
 /* One Lloyd step, hf_kf.py:454-459 / alf.py:242-245: importance-weighted centroids of the
  * NON-EMPTY clusters of `assign` (compacted in label order, hf_kf.py:294-296, alf.py:155-157),
@@ -221,6 +230,9 @@ int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn,
 int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double* nn, const float* s,
                           const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
                           double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream);
+int nif_kmeans_lloyd_step_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, const float* s,
+                               const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
+                               double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream);
 
 /* KF empty-cluster repair, hf_kf.py:466-471, in place; *changed = (assign != prev).any(). */
 int nif_kmeans_repair_kf(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N,

@@ -24,6 +24,14 @@
 
 namespace nif {
 
+// Entry (i, j) of the Gram matrix: with f32 storage the diagonal comes from its own f64 array (gd), so that the
+// distance of a neuron to a centroid made of that neuron alone cancels exactly, as it does with f64 storage.
+template <typename GT>
+__device__ __forceinline__ double gram_at(const GT* __restrict__ row, int i, int j, const double* __restrict__ gd) {
+  if (sizeof(GT) == 4) return i == j ? gd[j] : (double)row[j];
+  return (double)row[j];
+}
+
 // ---- block-wide arg-extremum over (value, index): larger value wins, lower index on ties -----
 __device__ __forceinline__ void block_argmax(double& v, int& j, double* sv, int* sj) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -52,7 +60,8 @@ __device__ __forceinline__ void block_argmax(double& v, int& j, double* sv, int*
 // picks[0] = first; picks[c] = argmax_j min_{c' < c} dist(centroid c', neuron j), where centroid c'
 // is the PROJECTED neuron picks[c'] and dist^2 = G[p][p] - 2 G[p][j] + nn[j].  Also leaves the
 // first assignment (argmin over all k centroids, lowest centroid on ties, :440-441).
-__global__ __launch_bounds__(1024) void kmeans_farthest_init_kernel(const double* __restrict__ G, int64_t ldg,
+template <typename GT>
+__global__ __launch_bounds__(1024) void kmeans_farthest_init_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                                                     const double* __restrict__ nn, int N, int k,
                                                                     int first, int* __restrict__ picks,
                                                                     int* __restrict__ assign,
@@ -62,12 +71,12 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_kernel(const double
   int idx = first;
   for (int c = 0; c < k; ++c) {
     if (threadIdx.x == 0) picks[c] = idx;
-    const double* __restrict__ row = G + (int64_t)idx * ldg;
-    const double gii = row[idx];
+    const GT* __restrict__ row = G + (int64_t)idx * ldg;
+    const double gii = gram_at(row, idx, idx, gd);
     double bv = -INFINITY;
     int bj = INT_MAX;
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
-      double d2 = gii - 2.0 * row[j] + nn[j];
+      double d2 = gii - 2.0 * gram_at(row, idx, j, gd) + nn[j];
       if (!(d2 > 0.0)) d2 = 0.0;
       const double d = sqrt(d2);
       double m = d;
@@ -93,8 +102,8 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_kernel(const double
 
 // Same, with the running minimum distance, |y_j|^2 and the label of every neuron held in registers (EPT
 // neurons per lane, N <= 1024 * EPT): a pick then only streams one Gram row.
-template <int EPT>
-__global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const double* __restrict__ G, int64_t ldg,
+template <int EPT, typename GT>
+__global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                                                         const double* __restrict__ nn, int N, int k,
                                                                         int first, int* __restrict__ picks,
                                                                         int* __restrict__ assign,
@@ -113,15 +122,15 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const do
   int idx = first;
   for (int c = 0; c < k; ++c) {
     if (threadIdx.x == 0) picks[c] = idx;
-    const double* __restrict__ row = G + (int64_t)idx * ldg;
-    const double gii = row[idx];
+    const GT* __restrict__ row = G + (int64_t)idx * ldg;
+    const double gii = gram_at(row, idx, idx, gd);
     double bv = -INFINITY;
     int bj = INT_MAX;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
       const int j = threadIdx.x + q * 1024;
       if (j < N) {
-        double d2 = gii - 2.0 * row[j] + nj[q];
+        double d2 = gii - 2.0 * gram_at(row, idx, j, gd) + nj[q];
         if (!(d2 > 0.0)) d2 = 0.0;
         const double d = sqrt(d2);
         if (c == 0 || d < md[q]) {
@@ -162,8 +171,8 @@ constexpr int FI_REGION_WORDS = FI_GRANULES + 32;       // + timeout word, padde
 constexpr int FI_REGIONS = 64;                          // calls in flight at once (each takes the next region)
 static __device__ __align__(256) unsigned long long fi_mailbox[FI_REGIONS * FI_REGION_WORDS];
 
-template <int EPT>
-__global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const double* __restrict__ G, int64_t ldg,
+template <int EPT, typename GT>
+__global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                                                           const double* __restrict__ nn, int N, int k,
                                                                           int first, int span, int* __restrict__ picks,
                                                                           int* __restrict__ assign,
@@ -190,15 +199,15 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const 
   int c = 0;
   for (; c < k; ++c) {
     if (b == 0 && tid == 0) picks[c] = idx;
-    const double* __restrict__ row = G + (int64_t)idx * ldg;
-    const double gii = row[idx];
+    const GT* __restrict__ row = G + (int64_t)idx * ldg;
+    const double gii = gram_at(row, idx, idx, gd);
     double bv = -INFINITY;
     int bj = INT_MAX;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
       const int j = j0 + tid + q * 1024;
       if (tid + q * 1024 < span && j < N) {
-        double d2 = gii - 2.0 * row[j] + nj[q];
+        double d2 = gii - 2.0 * gram_at(row, idx, j, gd) + nj[q];
         if (!(d2 > 0.0)) d2 = 0.0;
         const double d = sqrt(d2);
         if (c == 0 || d < md[q]) {
@@ -273,7 +282,8 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const 
 
 // ---- first assignment from neurons used as centroids (alf.py:221-229) ------------------------------
 // centroid c = neuron c0 + c; assign[j] = argmin_c G[cc][cc] - 2 G[cc][j] + nn[j] (lowest c on ties).
-__global__ void kmeans_assign_to_neurons_kernel(const double* __restrict__ G, int64_t ldg,
+template <typename GT>
+__global__ void kmeans_assign_to_neurons_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                                 const double* __restrict__ nn, int N, int k, int c0,
                                                 int* __restrict__ assign) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,7 +293,8 @@ __global__ void kmeans_assign_to_neurons_kernel(const double* __restrict__ G, in
   int bc = 0;
   for (int c = 0; c < k; ++c) {
     const int cc = c0 + c;
-    double d2 = G[(int64_t)cc * ldg + cc] - 2.0 * G[(int64_t)cc * ldg + j] + nj;
+    const GT* __restrict__ row = G + (int64_t)cc * ldg;
+    double d2 = gram_at(row, cc, cc, gd) - 2.0 * gram_at(row, cc, j, gd) + nj;
     if (!(d2 > 0.0)) d2 = 0.0;
     if (d2 < best) {
       best = d2;
@@ -358,12 +369,20 @@ __global__ __launch_bounds__(256) void kmeans_members_kernel(const int* __restri
   const int lane = threadIdx.x & 63;
   int at = seg[c];
   const int end = seg[c + 1];
-  for (int i0 = 0; i0 < N && at < end; i0 += 64) {
-    const int i = i0 + lane;
-    const bool mine = i < N && assign[i] == c;
-    const unsigned long long m = __ballot(mine);
-    if (mine) order[at + __popcll(m & ((1ull << lane) - 1ull))] = i;
-    at += __popcll(m);
+  for (int i0 = 0; i0 < N && at < end; i0 += 512) {  // eight label loads in flight per lane
+    int lab[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 64 + lane;
+      lab[u] = i < N ? assign[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool mine = lab[u] == c;
+      const unsigned long long m = __ballot(mine);
+      if (mine) order[at + __popcll(m & ((1ull << lane) - 1ull))] = i0 + u * 64 + lane;
+      at += __popcll(m);
+    }
   }
 }
 
@@ -481,6 +500,134 @@ __global__ __launch_bounds__(64) void kmeans_cost_kernel(const double* __restric
   for (int b = threadIdx.x; b < nblocks; b += 64) t += partial[b];
   t = wave_sum_f64(t);
   if (threadIdx.x == 0) *cost = t;
+}
+
+// ---- Lloyd step without H ------------------------------------------------------------------------------------
+// The step above writes H (k x N f64) and reads it back.  Only two things are needed from it: the k centroid norms,
+// which use H[c][i] for i INSIDE cluster c alone (sum of n_c^2 Gram entries, a sliver of G), and one running minimum
+// per neuron.  So: hself[i] = H[c(i)][i] first, the norms from it, then ONE pass over G that forms every H[c][j] in
+// registers, turns it into a distance and keeps the minimum.  Same sums in the same order, same division: the
+// assignment, distances and cost carry the same bits as the H-based step, with 8 N^2 (f64 G) or 4 N^2 (f32 G) bytes
+// of traffic instead of 8 N^2 + 16 k N.
+template <typename GT>
+__global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
+                                    const float* __restrict__ s,
+                                    const int* __restrict__ order, const int* __restrict__ assign,
+                                    const int* __restrict__ seg, const int* __restrict__ compact,
+                                    const double* __restrict__ S, int N, double* __restrict__ hself) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // sorted position: a wave's lanes share clusters
+  if (t >= N) return;
+  const int i = order[t];
+  const int c = assign[i];
+  double acc = 0.0;
+  for (int u = seg[c]; u < seg[c + 1]; ++u) {
+    const int ip = order[u];
+    acc += (double)s[ip] * gram_at(G + (int64_t)ip * ldg, ip, i, gd);
+  }
+  hself[i] = acc / S[compact[c]];
+}
+
+// cn[cc] = sum_{i in c} s_i hself[i] / S_c in kmeans_cn_kernel's order; one wavefront per cluster
+__global__ void kmeans_cn_self_kernel(const double* __restrict__ hself, const float* __restrict__ s,
+                                      const int* __restrict__ order, const int* __restrict__ seg,
+                                      const int* __restrict__ compact, const double* __restrict__ S, int k,
+                                      double* __restrict__ cn) {
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= k) return;
+  const int cc = compact[c];
+  if (cc < 0) return;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (int t = seg[c] + lane; t < seg[c + 1]; t += 64) {
+    const int i = order[t];
+    acc += (double)s[i] * hself[i];
+  }
+  acc = wave_sum_f64(acc);
+  if (lane == 0) cn[cc] = acc / S[cc];
+}
+
+// ssorted[t] = s[order[t]]: the member weights in the order the pass below walks them
+__global__ void kmeans_ssorted_kernel(const float* __restrict__ s, const int* __restrict__ order, int N,
+                                      float* __restrict__ ssorted) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < N) ssorted[t] = s[order[t]];
+}
+
+// Block = 64 neurons x 16 wavefronts; wavefront y takes the y-th sixteenth of the labels (a contiguous run of
+// `order`, read through the scalar unit), forms H[c][j] for its 64 neurons member row by member row (256 or 512
+// contiguous bytes of G per row) and keeps the smallest distance; the 16 candidates are merged in LDS, lowest compact
+// label on ties as in kmeans_nearest_kernel.
+template <typename GT>
+__global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
+    const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd, const float* __restrict__ ssorted,
+    const int* __restrict__ order, const int* __restrict__ seg, const int* __restrict__ compact,
+    const double* __restrict__ S,
+    const double* __restrict__ cn, const double* __restrict__ nn, const float* __restrict__ s, int N, int k,
+    int* __restrict__ assign_out, double* __restrict__ nearest, double* __restrict__ partial) {
+  __shared__ double cand_v[16][64];
+  __shared__ int cand_c[16][64];
+  const int tx = threadIdx.x & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * 64 + tx;
+  const int jc = j < N ? j : N - 1;  // lanes past the end compute a valid column and drop it
+  const int per = (k + 15) / 16;
+  const int c_lo = ty * per, c_hi = min(k, c_lo + per);
+  const double nj = nn[jc];
+  const double gjj = sizeof(GT) == 4 ? gd[jc] : 0.0;  // f32 storage: the diagonal entry comes from its f64 array
+  const GT* __restrict__ col = G + jc;
+  double best = INFINITY;
+  int bc = INT_MAX;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int cc = compact[c];
+    if (cc < 0) continue;
+    const int b = seg[c], e = seg[c + 1];
+    double acc = 0.0;
+    int t = b;
+    for (; t + 8 <= e; t += 8) {
+      double g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = order[t + u];
+        const double gv = (double)col[(int64_t)i * ldg];
+        g[u] = (sizeof(GT) == 4 && i == jc) ? gjj : gv;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)ssorted[t + u] * g[u];
+    }
+    for (; t < e; ++t) {
+      const int i = order[t];
+      const double gv = (double)col[(int64_t)i * ldg];
+      acc += (double)ssorted[t] * ((sizeof(GT) == 4 && i == jc) ? gjj : gv);
+    }
+    const double d2 = cn[cc] - 2.0 * (acc / S[cc]) + nj;
+    if (d2 < best) {
+      best = d2;
+      bc = cc;
+    }
+  }
+  cand_v[ty][tx] = best;
+  cand_c[ty][tx] = bc;
+  __syncthreads();
+  if (ty != 0) return;
+  for (int y = 1; y < 16; ++y) {
+    const double ov = cand_v[y][tx];
+    const int oc = cand_c[y][tx];
+    if (ov < best || (ov == best && oc < bc)) {
+      best = ov;
+      bc = oc;
+    }
+  }
+  double contrib = 0.0;
+  if (j < N) {
+    if (bc == INT_MAX) bc = 0;
+    if (!(best > 0.0)) best = 0.0;
+    const double d = sqrt(best);
+    assign_out[j] = bc;
+    nearest[j] = d;
+    contrib = (double)s[j] * d;
+  }
+  contrib = wave_sum_f64(contrib);
+  if (tx == 0) partial[blockIdx.x] = contrib;
 }
 
 // ---- KF empty-cluster repair (hf_kf.py:466-471), one workgroup --------------------------------------
@@ -863,7 +1010,7 @@ static bool km_launch_sw(int64_t blocks, hipStream_t st, const float* A, int64_t
 }
 
 struct KmWs {
-  size_t off_rank, off_counts, off_seg, off_compact, off_order, off_H, off_S, off_cn, off_partial, off_pos, off_wsorted, total;
+  size_t off_rank, off_counts, off_seg, off_compact, off_order, off_H, off_S, off_cn, off_partial, off_pos, off_wsorted, off_hself, total;
   int nblk;
 };
 static inline size_t ka(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -881,6 +1028,7 @@ static KmWs km_ws(int N, int k) {
   w.off_partial = o; o += ka((size_t)((N + 63) / 64) * 8);
   w.off_pos = o; o += ka((size_t)N * 4);
   w.off_wsorted = o; o += ka((size_t)N * 4);
+  w.off_hself = o; o += ka((size_t)N * 8);
   w.off_H = o; o += ka((size_t)k * N * 8);
   w.total = o;
   return w;
@@ -905,14 +1053,18 @@ extern "C" size_t nif_kmeans_workspace_bytes(int N, int k) {
   return nif::km_ws(N, k).total;
 }
 
-extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const double* nn, int N, int k, int first,
-                                        int32_t* picks, int32_t* assign, double* mind, void* stream) {
-  if (!G || !nn || !picks || !assign || !mind || N <= 0 || k <= 0 || ldg < N || first < 0 || first >= N)
+namespace nif {
+
+template <typename GT>
+static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const double* nn, int N, int k, int first, int32_t* picks,
+                            int32_t* assign, double* mind, void* stream) {
+  if (!G || !nn || !picks || !assign || !mind || N <= 0 || k <= 0 || ldg < N || first < 0 || first >= N ||
+      (sizeof(GT) == 4 && !gd))
     return NIF_ERR_INVALID_ARG;
-  nif::clear_err();
+  clear_err();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static const int fi_single = nif::env_int("NIF_KMEANS_INIT_SINGLE_WG");  // tuning aid: keep the one-workgroup kernel
-  if (N > 4096 && N <= nif::FI_MAX_WG * 4096 && !fi_single) {
+  static const int fi_single = env_int("NIF_KMEANS_INIT_SINGLE_WG");  // tuning aid: keep the one-workgroup kernel
+  if (N > 4096 && N <= FI_MAX_WG * 4096 && !fi_single) {
     // several workgroups, one mailbox exchange per pick (see kmeans_farthest_init_multi_kernel)
     static std::mutex mu;
     static unsigned long long* base[64];
@@ -924,29 +1076,29 @@ extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const doub
       std::lock_guard<std::mutex> lk(mu);
       if (!base[dev]) {
         void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(nif::fi_mailbox)) != hipSuccess || !p) return NIF_ERR_NO_DEVICE;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(fi_mailbox)) != hipSuccess || !p) return NIF_ERR_NO_DEVICE;
         base[dev] = reinterpret_cast<unsigned long long*>(p);
       }
-      region = base[dev] + (size_t)(seq++ % nif::FI_REGIONS) * nif::FI_REGION_WORDS;
+      region = base[dev] + (size_t)(seq++ % FI_REGIONS) * FI_REGION_WORDS;
     }
     int B = (N + 2047) / 2048;            // two neurons per lane where that fills <= 16 workgroups
-    if (B > nif::FI_MAX_WG) B = nif::FI_MAX_WG;
+    if (B > FI_MAX_WG) B = FI_MAX_WG;
     const int span = (N + B - 1) / B;
     const int ept = (span + 1023) / 1024;
-    if (hipMemsetAsync(region, 0, nif::FI_REGION_WORDS * sizeof(unsigned long long), st) != hipSuccess) return NIF_ERR_LAUNCH;
-#define NIF_FIM_GO(E)                                                                                                \
-  hipLaunchKernelGGL(nif::kmeans_farthest_init_multi_kernel<E>, dim3(B), dim3(1024), 0, st, G, ldg, nn, N, k, first, span, \
-                     picks, assign, mind, region)
+    if (hipMemsetAsync(region, 0, FI_REGION_WORDS * sizeof(unsigned long long), st) != hipSuccess) return NIF_ERR_LAUNCH;
+#define NIF_FIM_GO(E)                                                                                                 \
+  hipLaunchKernelGGL((kmeans_farthest_init_multi_kernel<E, GT>), dim3(B), dim3(1024), 0, st, G, ldg, gd, nn, N, k,   \
+                     first, span, picks, assign, mind, region)
     if (ept <= 1) NIF_FIM_GO(1);
     else if (ept <= 2) NIF_FIM_GO(2);
     else NIF_FIM_GO(4);
 #undef NIF_FIM_GO
-    return nif::launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+    return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
   }
   const int ept = (N + 1023) / 1024;
-#define NIF_FI_GO(E) \
-  hipLaunchKernelGGL(nif::kmeans_farthest_init_reg_kernel<E>, dim3(1), dim3(1024), 0, st, G, ldg, nn, N, k, first, picks, \
-                     assign, mind)
+#define NIF_FI_GO(E)                                                                                                   \
+  hipLaunchKernelGGL((kmeans_farthest_init_reg_kernel<E, GT>), dim3(1), dim3(1024), 0, st, G, ldg, gd, nn, N, k, first, \
+                     picks, assign, mind)
   if (ept <= 1) NIF_FI_GO(1);
   else if (ept <= 2) NIF_FI_GO(2);
   else if (ept <= 4) NIF_FI_GO(4);
@@ -954,26 +1106,29 @@ extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const doub
   else if (ept <= 16) NIF_FI_GO(16);
   else if (ept <= 32) NIF_FI_GO(32);
   else
-    hipLaunchKernelGGL(nif::kmeans_farthest_init_kernel, dim3(1), dim3(1024), 0, st, G, ldg, nn, N, k, first, picks,
+    hipLaunchKernelGGL(kmeans_farthest_init_kernel<GT>, dim3(1), dim3(1024), 0, st, G, ldg, gd, nn, N, k, first, picks,
                        assign, mind);
 #undef NIF_FI_GO
-  return nif::launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 
-extern "C" int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn, int N, int k, int c0,
-                                            int32_t* assign, void* stream) {
-  if (!G || !nn || !assign || N <= 0 || k <= 0 || ldg < N || c0 < 0 || c0 + k > N) return NIF_ERR_INVALID_ARG;
-  nif::clear_err();
-  hipLaunchKernelGGL(nif::kmeans_assign_to_neurons_kernel, dim3((N + 255) / 256), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), G, ldg, nn, N, k, c0, assign);
-  return nif::launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+template <typename GT>
+static int km_assign_to_neurons(const GT* G, int64_t ldg, const double* gd, const double* nn, int N, int k, int c0,
+                                int32_t* assign, void* stream) {
+  if (!G || !nn || !assign || N <= 0 || k <= 0 || ldg < N || c0 < 0 || c0 + k > N || (sizeof(GT) == 4 && !gd))
+    return NIF_ERR_INVALID_ARG;
+  clear_err();
+  hipLaunchKernelGGL(kmeans_assign_to_neurons_kernel<GT>, dim3((N + 255) / 256), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), G, ldg, gd, nn, N, k, c0, assign);
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 
-extern "C" int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double* nn, const float* s,
-                                     const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
-                                     double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
-  using namespace nif;
-  if (!G || !nn || !s || !assign || !assign_out || !nearest || !cost || !kprime || N <= 0 || k <= 0 || ldg < N)
+template <typename GT>
+static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const double* nn, const float* s, const int32_t* assign, int N, int k,
+                         int32_t* assign_out, double* nearest, double* cost, int32_t* kprime, void* ws, size_t ws_bytes,
+                         void* stream) {
+  if (!G || !nn || !s || !assign || !assign_out || !nearest || !cost || !kprime || N <= 0 || k <= 0 || ldg < N ||
+      (sizeof(GT) == 4 && !gd))
     return NIF_ERR_INVALID_ARG;
   const KmWs w = km_ws(N, k);
   if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
@@ -983,20 +1138,84 @@ extern "C" int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double*
   int* seg = reinterpret_cast<int*>(b + w.off_seg);
   int* compact = reinterpret_cast<int*>(b + w.off_compact);
   int* order = reinterpret_cast<int*>(b + w.off_order);
-  double* H = reinterpret_cast<double*>(b + w.off_H);
   double* S = reinterpret_cast<double*>(b + w.off_S);
   double* cn = reinterpret_cast<double*>(b + w.off_cn);
   double* partial = reinterpret_cast<double*>(b + w.off_partial);
-  km_group(assign, N, k, w, b, kprime, st);
-  prof_begin(NIF_PROF_KMEANS, st);
-  hipLaunchKernelGGL(kmeans_H_kernel, dim3(w.nblk, k), dim3(256), 0, st, G, ldg, s, order, seg, compact, N, H, S);
-  prof_end(NIF_PROF_KMEANS, st);
-  hipLaunchKernelGGL(kmeans_cn_kernel, dim3((k + 3) / 4), dim3(256), 0, st, H, s, order, seg, compact, S, N, k, cn);
+  double* hself = reinterpret_cast<double*>(b + w.off_hself);
+  float* ssorted = reinterpret_cast<float*>(b + w.off_wsorted);
   const int nb64 = (N + 63) / 64;
-  hipLaunchKernelGGL(kmeans_nearest_kernel, dim3(nb64), dim3(1024), 0, st, H, cn, nn, s, kprime, N, assign_out,
-                     nearest, partial);
+  km_group(assign, N, k, w, b, kprime, st);
+  hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256), dim3(256), 0, st, s, order, seg, compact, k, S);
+  hipLaunchKernelGGL(kmeans_ssorted_kernel, dim3(w.nblk), dim3(256), 0, st, s, order, N, ssorted);
+  hipLaunchKernelGGL(kmeans_hself_kernel<GT>, dim3(w.nblk), dim3(256), 0, st, G, ldg, gd, s, order, assign, seg, compact, S,
+                     N, hself);
+  hipLaunchKernelGGL(kmeans_cn_self_kernel, dim3((k + 3) / 4), dim3(256), 0, st, hself, s, order, seg, compact, S, k, cn);
+  prof_begin(NIF_PROF_KMEANS, st);
+  hipLaunchKernelGGL(kmeans_nearest_fused_kernel<GT>, dim3(nb64), dim3(1024), 0, st, G, ldg, gd, ssorted, order, seg,
+                     compact, S, cn, nn, s, N, k, assign_out, nearest, partial);
+  prof_end(NIF_PROF_KMEANS, st);
   hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1), dim3(64), 0, st, partial, nb64, cost);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+}
+
+}  // namespace nif
+
+extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const double* nn, int N, int k, int first,
+                                        int32_t* picks, int32_t* assign, double* mind, void* stream) {
+  return nif::km_farthest_init<double>(G, ldg, nullptr, nn, N, k, first, picks, assign, mind, stream);
+}
+extern "C" int nif_kmeans_farthest_init_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, int N,
+                                             int k, int first, int32_t* picks, int32_t* assign, double* mind,
+                                             void* stream) {
+  return nif::km_farthest_init<float>(G, ldg, gdiag, nn, N, k, first, picks, assign, mind, stream);
+}
+
+extern "C" int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn, int N, int k, int c0,
+                                            int32_t* assign, void* stream) {
+  return nif::km_assign_to_neurons<double>(G, ldg, nullptr, nn, N, k, c0, assign, stream);
+}
+extern "C" int nif_kmeans_assign_to_neurons_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
+                                                 int N, int k, int c0, int32_t* assign, void* stream) {
+  return nif::km_assign_to_neurons<float>(G, ldg, gdiag, nn, N, k, c0, assign, stream);
+}
+
+extern "C" int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double* nn, const float* s,
+                                     const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
+                                     double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
+  if (nif::env_int("NIF_KMEANS_LLOYD_H")) {  // A/B aid: the step that materialises H
+    using namespace nif;
+    if (!G || !nn || !s || !assign || !assign_out || !nearest || !cost || !kprime || N <= 0 || k <= 0 || ldg < N)
+      return NIF_ERR_INVALID_ARG;
+    const KmWs w = km_ws(N, k);
+    if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    clear_err();
+    unsigned char* b = reinterpret_cast<unsigned char*>(ws);
+    int* seg = reinterpret_cast<int*>(b + w.off_seg);
+    int* compact = reinterpret_cast<int*>(b + w.off_compact);
+    int* order = reinterpret_cast<int*>(b + w.off_order);
+    double* H = reinterpret_cast<double*>(b + w.off_H);
+    double* S = reinterpret_cast<double*>(b + w.off_S);
+    double* cn = reinterpret_cast<double*>(b + w.off_cn);
+    double* partial = reinterpret_cast<double*>(b + w.off_partial);
+    km_group(assign, N, k, w, b, kprime, st);
+    prof_begin(NIF_PROF_KMEANS, st);
+    hipLaunchKernelGGL(kmeans_H_kernel, dim3(w.nblk, k), dim3(256), 0, st, G, ldg, s, order, seg, compact, N, H, S);
+    prof_end(NIF_PROF_KMEANS, st);
+    hipLaunchKernelGGL(kmeans_cn_kernel, dim3((k + 3) / 4), dim3(256), 0, st, H, s, order, seg, compact, S, N, k, cn);
+    const int nb64 = (N + 63) / 64;
+    hipLaunchKernelGGL(kmeans_nearest_kernel, dim3(nb64), dim3(1024), 0, st, H, cn, nn, s, kprime, N, assign_out,
+                       nearest, partial);
+    hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1), dim3(64), 0, st, partial, nb64, cost);
+    return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+  }
+  return nif::km_lloyd_step<double>(G, ldg, nullptr, nn, s, assign, N, k, assign_out, nearest, cost, kprime, ws, ws_bytes, stream);
+}
+extern "C" int nif_kmeans_lloyd_step_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
+                                          const float* s,
+                                          const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
+                                          double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
+  return nif::km_lloyd_step<float>(G, ldg, gdiag, nn, s, assign, N, k, assign_out, nearest, cost, kprime, ws, ws_bytes, stream);
 }
 
 extern "C" int nif_kmeans_repair_kf(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N,

@@ -258,7 +258,8 @@ class ALFusion:
 
         # one symmetric Gram of the clustering vectors; everything below streams it
         G, _, _ = ops.xty(kmeans_acts, None, acc='f32', norms=False, rows_sharded=True)
-        km = ops.KMeans(G, torch.diagonal(G).contiguous(), sample_weight, target_width)
+        Gs, gdiag = ops.kmeans_gram_storage(G)
+        km = ops.KMeans(Gs, gdiag, sample_weight, target_width, gdiag=gdiag)
 
         time_cc, iters = 0.0, 0
         best_total_cost, best_assignment = float('inf'), None

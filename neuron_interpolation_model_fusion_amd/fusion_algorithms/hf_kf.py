@@ -160,7 +160,8 @@ class LSFusion:
             best_assignment = identity
         else:
             GP, _, _ = ops.xty(R, W, acc='f64', norms=False)  # (XW)^T (XW) = R^T W
-            km = ops.KMeans(GP, na, s, output_size)
+            GP, gdiag = ops.kmeans_gram_storage(GP)
+            km = ops.KMeans(GP, na, s, output_size, gdiag=gdiag)
             best_assignment, best_total_cost = identity, np.inf
             start = time.time()
             # The tries are independent, so they advance in lock step: every round launches one Lloyd step and one
@@ -172,7 +173,7 @@ class LSFusion:
             main_stream = torch.cuda.current_stream(dev)
             for t in range(num_k_means_tries):
                 first = int(np.random.randint(low=0, high=output_size))  # a neuron of model 0 (:424)
-                solver = km if t == 0 else ops.KMeans(GP, na, s, output_size)  # own workspace per try
+                solver = km if t == 0 else ops.KMeans(GP, na, s, output_size, gdiag=gdiag)  # own workspace per try
                 # the farthest-point pass is one workgroup walking k picks: the tries run side by side on their
                 # own streams (one CU each) instead of queueing behind each other
                 side = torch.cuda.Stream(dev)

@@ -5,6 +5,7 @@ runs in libnif.so.  Inputs must live on a HIP device: there is no CPU path.
 """
 import ctypes
 
+import os
 import torch
 
 from . import _lib
@@ -447,7 +448,9 @@ def ls_solve(X, A, normalize=False):
     # sample-sharded: m is the GLOBAL row count for pinv's cutoff, and the dual form would need every row locally,
     # so the d x d normal equations are reduced and solved on every rank (identical inputs -> identical results)
     import torch.distributed as dist
+    from .parallel import _settle
     mt = torch.tensor([m], device=X.device, dtype=torch.int64)
+    _settle(mt, SampleSharding._active.group)
     dist.all_reduce(mt, group=SampleSharding._active.group)
     m = int(mt.item())
     R, _, na = xty(X, A, acc='f64', rows_sharded=True)
@@ -485,17 +488,38 @@ def refit_pairs(W, col, s0, s1, n0):
 
 # ---- Gram-form k-means --------------------------------------------------------------------------------
 
-class KMeans:
-    """Device state of one Gram-form k-means problem (see nif_kmeans_* in include/nif.h)."""
+def kmeans_gram_storage(G):
+    """(G as the k-means kernels stream it, its f64 diagonal): G rounded once to f32 (half the bytes of every Lloyd
+    step and every farthest-point pick; products and sums stay f64, the diagonal stays exact), or left in f64 with
+    NIF_KMEANS_G=f64.  The reference measures these distances in f32 itself (torch.cdist); all its goldens give the
+    same labels either way."""
+    gdiag = torch.diagonal(G).to(torch.float64).contiguous()
+    if G.dtype == torch.float64 and os.environ.get('NIF_KMEANS_G', 'f32') != 'f64':
+        return G.float(), gdiag
+    return G, gdiag
 
-    def __init__(self, G, nn, s, k):
+
+class KMeans:
+    """Device state of one Gram-form k-means problem (see nif_kmeans_* in include/nif.h).  G: N x N f64, or f32 with
+    its unrounded diagonal in `gdiag` (taken from G itself when not given)."""
+
+    def __init__(self, G, nn, s, k, gdiag=None):
         _need_gpu(G, nn)
-        self.G = None if G is None else G.contiguous()  # None: only centroid_weights() may be used
+        self.G = None if G is None else G.contiguous()  # None: only centroid_weights() / targets() may be used
+        if self.G is not None and self.G.dtype not in (torch.float32, torch.float64):
+            raise TypeError(f'KMeans: G must be float32 or float64, got {self.G.dtype}')
+        self._f32 = self.G is not None and self.G.dtype == torch.float32
+        self._sfx = '_gf32' if self._f32 else ''
         self.dev = nn.device
         self.N = nn.shape[0]
         self.k = int(k)
         self.nn = nn.to(device=self.dev, dtype=torch.float64).contiguous()
         self.s = s.to(device=self.dev, dtype=torch.float32).contiguous()
+        self._g = ()
+        if self._f32:
+            gd = torch.diagonal(self.G) if gdiag is None else gdiag
+            self.gdiag = gd.to(device=self.dev, dtype=torch.float64).contiguous()
+            self._g = (_ptr(self.gdiag),)
         with torch.cuda.device(self.dev):
             self.nbytes = lib.nif_kmeans_workspace_bytes(self.N, self.k)
             self.ws = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=self.dev)
@@ -508,16 +532,17 @@ class KMeans:
         """(picks, assign) of the KF farthest-point initialisation started at neuron `first`."""
         with torch.cuda.device(self.dev):
             picks, assign = self._i32(self.k), self._i32(self.N)
-            check(lib.nif_kmeans_farthest_init(_ptr(self.G), self.G.stride(0), _ptr(self.nn), self.N, self.k,
-                                               int(first), _ptr(picks), _ptr(assign), _ptr(self.mind), _stream()),
-                  'nif_kmeans_farthest_init')
+            fn = getattr(lib, 'nif_kmeans_farthest_init' + self._sfx)
+            check(fn(_ptr(self.G), self.G.stride(0), *self._g, _ptr(self.nn), self.N, self.k, int(first), _ptr(picks),
+                     _ptr(assign), _ptr(self.mind), _stream()), 'nif_kmeans_farthest_init' + self._sfx)
         return picks, assign
 
     def assign_to_neurons(self, c0):
         with torch.cuda.device(self.dev):
             assign = self._i32(self.N)
-            check(lib.nif_kmeans_assign_to_neurons(_ptr(self.G), self.G.stride(0), _ptr(self.nn), self.N, self.k,
-                                                   int(c0), _ptr(assign), _stream()), 'nif_kmeans_assign_to_neurons')
+            fn = getattr(lib, 'nif_kmeans_assign_to_neurons' + self._sfx)
+            check(fn(_ptr(self.G), self.G.stride(0), *self._g, _ptr(self.nn), self.N, self.k, int(c0), _ptr(assign),
+                     _stream()), 'nif_kmeans_assign_to_neurons' + self._sfx)
         return assign
 
     def lloyd_step(self, assign):
@@ -527,9 +552,10 @@ class KMeans:
             nearest = torch.empty(self.N, dtype=torch.float64, device=self.dev)
             cost = torch.empty((), dtype=torch.float64, device=self.dev)
             kprime = torch.empty((), dtype=torch.int32, device=self.dev)
-            check(lib.nif_kmeans_lloyd_step(_ptr(self.G), self.G.stride(0), _ptr(self.nn), _ptr(self.s), _ptr(assign),
-                                            self.N, self.k, _ptr(out), _ptr(nearest), _ptr(cost), _ptr(kprime),
-                                            _ptr(self.ws), self.nbytes, _stream()), 'nif_kmeans_lloyd_step')
+            fn = getattr(lib, 'nif_kmeans_lloyd_step' + self._sfx)
+            check(fn(_ptr(self.G), self.G.stride(0), *self._g, _ptr(self.nn), _ptr(self.s), _ptr(assign), self.N, self.k,
+                     _ptr(out), _ptr(nearest), _ptr(cost), _ptr(kprime), _ptr(self.ws), self.nbytes, _stream()),
+                  'nif_kmeans_lloyd_step' + self._sfx)
         return out, nearest, cost, kprime
 
     def repair_kf(self, assign, nearest, prev):

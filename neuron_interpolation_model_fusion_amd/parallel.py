@@ -49,6 +49,16 @@ def unpack_gram(buf, n0, n1, has_na=True, has_nb=True):
 TRI_BLOCK = 1024  # block rows of the packed upper triangle
 
 
+def _settle(t, group=None):
+    """gloo only (the CPU-side rehearsal backend; RCCL orders itself on the stream): finish this rank's queued GPU
+    work before handing a device tensor to the collective.  gloo stages device tensors through the host on streams
+    of its own; two ranks that share one GPU (tests/test_gpu_sharded.py, the bench rehearsal) otherwise wait on
+    each other's queued kernels from inside the collective, and were seen to stall there for minutes
+    (profiles/r2_gloo2_stall_stacks_before_fix.txt)."""
+    if t.is_cuda and dist.get_backend(group) != 'nccl':
+        torch.cuda.synchronize(t.device)
+
+
 def pack_gram_upper(G, na=None, block=None):
     """Symmetric G: only the block upper triangle travels (rows [i, i + block) from column i on), about half
     of the N^2 entries for N >> block -- at N = 24 576 (C5) 2.5 GB of f64 instead of 4.8 GB."""
@@ -86,10 +96,12 @@ def allreduce_gram(G, na=None, nb=None, group=None, symmetric=False):
     n0, n1 = G.shape
     if symmetric and n0 == n1 and n0 > 2 * TRI_BLOCK:
         buf = pack_gram_upper(G, na)
+        _settle(buf, group)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         G, na = unpack_gram_upper(buf, n0, na is not None)
         return G, na, (na if nb is not None else None)
     buf = pack_gram(G, na, nb)
+    _settle(buf, group)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return unpack_gram(buf, n0, n1, na is not None, nb is not None)
 
@@ -103,6 +115,7 @@ def allgather_rows(t, group=None):
     world = dist.get_world_size(group)
     rows = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     counts = [torch.empty_like(rows) for _ in range(world)]
+    _settle(rows, group)
     dist.all_gather(counts, rows, group=group)
     counts = [int(c.item()) for c in counts]
     longest = max(counts)
@@ -111,6 +124,7 @@ def allgather_rows(t, group=None):
         pad = torch.zeros((longest - mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
         mine = torch.cat([mine, pad], dim=0)
     parts = [torch.empty_like(mine) for _ in range(world)]
+    _settle(mine, group)
     dist.all_gather(parts, mine, group=group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
@@ -122,6 +136,7 @@ def broadcast_parameters(module, src=0, group=None):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
+            _settle(t, group)
             dist.broadcast(t.data, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
 
 

@@ -439,12 +439,19 @@ def _ref_lloyd(A, s, assign, k):
     return arg, nearest, float((nearest * s64).sum()), len(labels), cents
 
 
-@pytest.mark.parametrize('N,k,m,empty', [(50, 7, 40, ()), (300, 64, 64, (3, 10)), (1000, 130, 128, (0,)), (2500, 16, 96, ())])
+@pytest.mark.parametrize('N,k,m,empty', [(50, 7, 40, ()), (300, 64, 64, (3, 10)), (1000, 130, 128, (0,)), (2500, 16, 96, ()),
+                                         (5000, 40, 32, (7,))])
 def test_kmeans_lloyd_step_matches_f64_reference(ops, N, k, m, empty):
     A, s, assign = _kmeans_problem(N, k, m, N + k, empty)
     G, _, _ = ops.xty(A.double().cuda(), None, acc='f64', norms=False)
     km = ops.KMeans(G, torch.diagonal(G).contiguous(), s.cuda(), k)
     out, nearest, cost, kp = km.lloyd_step(assign.cuda())
+    # f32 storage of G (the fusions' default): same labels, distances within the rounding of G
+    km32 = ops.KMeans(G.float(), torch.diagonal(G).contiguous(), s.cuda(), k, gdiag=torch.diagonal(G))
+    out32, nearest32, cost32, kp32 = km32.lloyd_step(assign.cuda())
+    assert torch.equal(out32, out) and int(kp32) == int(kp)
+    np.testing.assert_allclose(nearest32.cpu().numpy(), nearest.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(float(cost32), float(cost), rtol=1e-6)
     arg, near, c, kprime, _ = _ref_lloyd(A, s, assign, k)
     assert int(kp) == kprime
     # ties within rounding aside (none in random data), the labels are exact
@@ -505,12 +512,15 @@ def test_kmeans_targets_bits_equal_sequential_f64_sums(ops, N, k, m):
     assert float(T[:, int(kp):].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('gdtype', [torch.float64, torch.float32])
 @pytest.mark.parametrize('N,k', [(64, 5), (300, 20), (3000, 33), (4097, 12), (6000, 40), (24576, 70), (40000, 6), (65536, 5), (70000, 4)])
-def test_kmeans_farthest_init_matches_sequential_reference(ops, N, k):
+def test_kmeans_farthest_init_matches_sequential_reference(ops, N, k, gdtype):
     g = torch.Generator().manual_seed(N)
     A = torch.randn(24, N, generator=g).double()
     P = A * 0.9  # "projected" vectors whose Gram feeds the picks; distances go to the raw vectors
-    G = (P.T @ P)
+    G = (P.T @ P).to(gdtype)
+    G_dev = G.cuda()
+    G = G.double()  # the kernels widen the stored entries and work in f64
     nn = (A * A).sum(0)
     # the kernel's distance: G[p][p] - 2 G[p][j] + nn[j]
     first = 3
@@ -525,7 +535,7 @@ def test_kmeans_farthest_init_matches_sequential_reference(ops, N, k):
             mind[upd], lab[upd] = d[upd], c
         if c + 1 < k:
             picks.append(int(torch.argmax(mind)))  # first index of the maximum
-    km = ops.KMeans(G.cuda(), nn.cuda(), torch.ones(N).cuda(), k)
+    km = ops.KMeans(G_dev, nn.cuda(), torch.ones(N).cuda(), k)
     got_picks, got_assign = km.farthest_init(first)
     assert got_picks.cpu().tolist() == picks
     assert (got_assign.cpu().long() == lab).all()

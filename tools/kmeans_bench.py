@@ -12,8 +12,11 @@ base = torch.randn(m, h, device='cuda', generator=g)
 A = torch.cat([base[:, torch.randperm(h, device='cuda')] + 0.4 * torch.randn(m, h, device='cuda', generator=g)
                for _ in range(models)], dim=1).contiguous()
 G, _, _ = ops.xty(A, None, norms=False)
+nn = torch.diagonal(G).contiguous()
+if os.environ.get('KM_G', 'f64') == 'f32':
+    G = G.float()
 w = torch.ones(N, device='cuda')
-km = ops.KMeans(G, torch.diagonal(G).contiguous(), w, k)
+km = ops.KMeans(G, nn, w, k, gdiag=nn)
 a = km.assign_to_neurons(0)
 for _ in range(3):
     a, nearest, cost, kp = km.lloyd_step(a)
@@ -30,6 +33,6 @@ t2 = time.perf_counter()
 picks, _ = km.farthest_init(0)
 torch.cuda.synchronize()
 t3 = time.perf_counter()
-print(f'{which}: N={N} k={k} m={m}: lloyd step {(t1 - t0) * 100:.3f} ms ({(8.0 * N * N + 16.0 * k * N) / (t1 - t0) * 10 / 1e9:.0f} GB/s), '
+print(f'{which} G {G.dtype}: N={N} k={k} m={m}: lloyd step {(t1 - t0) * 100:.3f} ms ({(4.0 * N * N + 4.0 * k * N) / (t1 - t0) * 10 / 1e9:.0f} GB/s), '
       f'targets {(t2 - t1) * 100:.3f} ms ({(4.0 * m * N + 4.0 * m * k) / (t2 - t1) * 10 / 1e9:.0f} GB/s), '
       f'farthest init {(t3 - t2) * 1e3:.1f} ms')
