@@ -10,7 +10,7 @@
 //     d^2(c, j)  = |c|^2 - 2 H[c][j] + nn[j]             (nn[j] = |y_j|^2, the neuron compared)
 // For KF x_i = X w_i is the LS projection of y_i = a_i and <X w_i, a_j> = <X w_i, X w_j>, so
 // G = (XW)^T (XW) and nn = |a_j|^2; for ALF x = y and nn = diag(G).
-// HBM-bound kernels: 8 N^2 bytes (G, f64) + 16 k N bytes (H written, read back) per step.
+// HBM-bound kernels: one pass over G per step, 8 N^2 bytes (f64 storage) or 4 N^2 (f32 storage, _gf32 entries).
 // Every reduction runs in a fixed order (members sorted by index), so results are reproducible.
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -398,101 +398,6 @@ __global__ void kmeans_S_kernel(const float* __restrict__ s, const int* __restri
   S[cc] = tot;
 }
 
-// H[cc][j] = sum_{i in c} s_i G[i][j] / S_c for the non-empty cluster c = blockIdx.y (cc = compact[c])
-__global__ void kmeans_H_kernel(const double* __restrict__ G, int64_t ldg, const float* __restrict__ s,
-                                const int* __restrict__ order, const int* __restrict__ seg,
-                                const int* __restrict__ compact, int N, double* __restrict__ H,
-                                double* __restrict__ S) {
-  const int c = blockIdx.y;
-  const int cc = compact[c];
-  if (cc < 0) return;
-  const int b = seg[c], e = seg[c + 1];
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  double tot = 0.0;
-  for (int t = b; t < e; ++t) tot += (double)s[order[t]];
-  if (j == 0) S[cc] = tot;
-  if (j >= N) return;
-  double acc = 0.0;
-  for (int t = b; t < e; ++t) {
-    const int i = order[t];
-    acc += (double)s[i] * G[(int64_t)i * ldg + j];
-  }
-  H[(int64_t)cc * N + j] = acc / tot;
-}
-
-// cn[cc] = sum_{i in c} s_i H[cc][i] / S_c; one wavefront per cluster
-__global__ void kmeans_cn_kernel(const double* __restrict__ H, const float* __restrict__ s,
-                                 const int* __restrict__ order, const int* __restrict__ seg,
-                                 const int* __restrict__ compact, const double* __restrict__ S, int N, int k,
-                                 double* __restrict__ cn) {
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (c >= k) return;
-  const int cc = compact[c];
-  if (cc < 0) return;
-  const int lane = threadIdx.x & 63;
-  double acc = 0.0;
-  for (int t = seg[c] + lane; t < seg[c + 1]; t += 64) {
-    const int i = order[t];
-    acc += (double)s[i] * H[(int64_t)cc * N + i];
-  }
-  acc = wave_sum_f64(acc);
-  if (lane == 0) cn[cc] = acc / S[cc];
-}
-
-// nearest centroid of every neuron (lowest compact label on ties, torch.min's first index),
-// distance, and per-block partial sums of s_j * distance in a fixed order.
-// Block = 64 neurons x 16 wavefronts; wavefront y scans centroids y, y + 16, ... (rows of H, coalesced),
-// then the 16 candidates of a neuron are merged in LDS.
-__global__ __launch_bounds__(1024) void kmeans_nearest_kernel(const double* __restrict__ H,
-                                                              const double* __restrict__ cn,
-                                                              const double* __restrict__ nn,
-                                                              const float* __restrict__ s,
-                                                              const int* __restrict__ kprime, int N,
-                                                              int* __restrict__ assign_out,
-                                                              double* __restrict__ nearest,
-                                                              double* __restrict__ partial) {
-  __shared__ double cand_v[16][64];
-  __shared__ int cand_c[16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + tx;
-  const int kp = *kprime;
-  double best = INFINITY;
-  int bc = INT_MAX;
-  if (j < N) {
-    const double nj = nn[j];
-    for (int cc = ty; cc < kp; cc += 16) {
-      const double d2 = cn[cc] - 2.0 * H[(int64_t)cc * N + j] + nj;
-      if (d2 < best) {
-        best = d2;
-        bc = cc;
-      }
-    }
-  }
-  cand_v[ty][tx] = best;
-  cand_c[ty][tx] = bc;
-  __syncthreads();
-  if (ty != 0) return;
-  for (int y = 1; y < 16; ++y) {
-    const double ov = cand_v[y][tx];
-    const int oc = cand_c[y][tx];
-    if (ov < best || (ov == best && oc < bc)) {
-      best = ov;
-      bc = oc;
-    }
-  }
-  double contrib = 0.0;
-  if (j < N) {
-    if (bc == INT_MAX) bc = 0;
-    if (!(best > 0.0)) best = 0.0;
-    const double d = sqrt(best);
-    assign_out[j] = bc;
-    nearest[j] = d;
-    contrib = (double)s[j] * d;
-  }
-  contrib = wave_sum_f64(contrib);
-  if (tx == 0) partial[blockIdx.x] = contrib;
-}
-
 // cost = sum of the per-block partials: lane l adds partial[l], partial[l + 64], ... in order, then a fixed tree
 __global__ __launch_bounds__(64) void kmeans_cost_kernel(const double* __restrict__ partial, int nblocks,
                                                          double* __restrict__ cost) {
@@ -502,13 +407,12 @@ __global__ __launch_bounds__(64) void kmeans_cost_kernel(const double* __restric
   if (threadIdx.x == 0) *cost = t;
 }
 
-// ---- Lloyd step without H ------------------------------------------------------------------------------------
-// The step above writes H (k x N f64) and reads it back.  Only two things are needed from it: the k centroid norms,
-// which use H[c][i] for i INSIDE cluster c alone (sum of n_c^2 Gram entries, a sliver of G), and one running minimum
-// per neuron.  So: hself[i] = H[c(i)][i] first, the norms from it, then ONE pass over G that forms every H[c][j] in
-// registers, turns it into a distance and keeps the minimum.  Same sums in the same order, same division: the
-// assignment, distances and cost carry the same bits as the H-based step, with 8 N^2 (f64 G) or 4 N^2 (f32 G) bytes
-// of traffic instead of 8 N^2 + 16 k N.
+// ---- Lloyd step: H is never stored ---------------------------------------------------------------------------
+// H[c][j] = sum_{i in c} s_i G[i][j] / S_c (k x N) is needed for two things only: the k centroid norms, which use
+// H[c][i] for i INSIDE cluster c alone (sum of n_c^2 Gram entries, a sliver of G), and one running minimum per
+// neuron.  So: hself[i] = H[c(i)][i] first, the norms from it, then ONE pass over G that forms every H[c][j] in
+// registers, turns it into a distance and keeps the minimum: 8 N^2 (f64 G) or 4 N^2 (f32 G) bytes per step.  (The
+// first version of this file wrote H and read it back, 16 k N bytes more; this pass gives the same bits.)
 template <typename GT>
 __global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                     const float* __restrict__ s,
@@ -1010,7 +914,7 @@ static bool km_launch_sw(int64_t blocks, hipStream_t st, const float* A, int64_t
 }
 
 struct KmWs {
-  size_t off_rank, off_counts, off_seg, off_compact, off_order, off_H, off_S, off_cn, off_partial, off_pos, off_wsorted, off_hself, total;
+  size_t off_rank, off_counts, off_seg, off_compact, off_order, off_wT, off_S, off_cn, off_partial, off_pos, off_wsorted, off_hself, total;
   int nblk;
 };
 static inline size_t ka(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1029,7 +933,7 @@ static KmWs km_ws(int N, int k) {
   w.off_pos = o; o += ka((size_t)N * 4);
   w.off_wsorted = o; o += ka((size_t)N * 4);
   w.off_hself = o; o += ka((size_t)N * 8);
-  w.off_H = o; o += ka((size_t)k * N * 8);
+  w.off_wT = o; o += ka((size_t)k * N * 4);  // member-major weights of nif_kmeans_targets: (largest cluster) x k
   w.total = o;
   return w;
 }
@@ -1182,33 +1086,6 @@ extern "C" int nif_kmeans_assign_to_neurons_gf32(const float* G, int64_t ldg, co
 extern "C" int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double* nn, const float* s,
                                      const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
                                      double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
-  if (nif::env_int("NIF_KMEANS_LLOYD_H")) {  // A/B aid: the step that materialises H
-    using namespace nif;
-    if (!G || !nn || !s || !assign || !assign_out || !nearest || !cost || !kprime || N <= 0 || k <= 0 || ldg < N)
-      return NIF_ERR_INVALID_ARG;
-    const KmWs w = km_ws(N, k);
-    if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    clear_err();
-    unsigned char* b = reinterpret_cast<unsigned char*>(ws);
-    int* seg = reinterpret_cast<int*>(b + w.off_seg);
-    int* compact = reinterpret_cast<int*>(b + w.off_compact);
-    int* order = reinterpret_cast<int*>(b + w.off_order);
-    double* H = reinterpret_cast<double*>(b + w.off_H);
-    double* S = reinterpret_cast<double*>(b + w.off_S);
-    double* cn = reinterpret_cast<double*>(b + w.off_cn);
-    double* partial = reinterpret_cast<double*>(b + w.off_partial);
-    km_group(assign, N, k, w, b, kprime, st);
-    prof_begin(NIF_PROF_KMEANS, st);
-    hipLaunchKernelGGL(kmeans_H_kernel, dim3(w.nblk, k), dim3(256), 0, st, G, ldg, s, order, seg, compact, N, H, S);
-    prof_end(NIF_PROF_KMEANS, st);
-    hipLaunchKernelGGL(kmeans_cn_kernel, dim3((k + 3) / 4), dim3(256), 0, st, H, s, order, seg, compact, S, N, k, cn);
-    const int nb64 = (N + 63) / 64;
-    hipLaunchKernelGGL(kmeans_nearest_kernel, dim3(nb64), dim3(1024), 0, st, H, cn, nn, s, kprime, N, assign_out,
-                       nearest, partial);
-    hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1), dim3(64), 0, st, partial, nb64, cost);
-    return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
-  }
   return nif::km_lloyd_step<double>(G, ldg, nullptr, nn, s, assign, N, k, assign_out, nearest, cost, kprime, ws, ws_bytes, stream);
 }
 extern "C" int nif_kmeans_lloyd_step_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
@@ -1288,7 +1165,7 @@ extern "C" int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const 
     const int cpt = k <= 1024 ? 1 : k <= 2048 ? 2 : k <= 3072 ? 3 : k <= 4096 ? 4 : 0;
     if (vec && !no_pipe && pf && cpt && !(pf == 9 && cpt == 4) && (int64_t)R * lda < (int64_t)1 << 31 && (size_t)R * N < 65536) {
       int* pos = reinterpret_cast<int*>(b + ww.off_pos);
-      float* wT = reinterpret_cast<float*>(b + ww.off_H);  // member-major weights: (largest cluster) x k floats <= k N 8 bytes
+      float* wT = reinterpret_cast<float*>(b + ww.off_wT);
       float* wsorted = reinterpret_cast<float*>(b + ww.off_wsorted);
       hipLaunchKernelGGL(kmeans_sorted_kernel, dim3((N + 255) / 256), dim3(256), 0, st, order, assign, seg, w, N, k, pos,
                          wsorted, wT);

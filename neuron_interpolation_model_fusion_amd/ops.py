@@ -448,11 +448,8 @@ def ls_solve(X, A, normalize=False):
     # sample-sharded: m is the GLOBAL row count for pinv's cutoff, and the dual form would need every row locally,
     # so the d x d normal equations are reduced and solved on every rank (identical inputs -> identical results)
     import torch.distributed as dist
-    from .parallel import _settle
-    mt = torch.tensor([m], device=X.device, dtype=torch.int64)
-    _settle(mt, SampleSharding._active.group)
-    dist.all_reduce(mt, group=SampleSharding._active.group)
-    m = int(mt.item())
+    from .parallel import all_reduce_sum
+    m = int(all_reduce_sum(torch.tensor([m], device=X.device, dtype=torch.int64), SampleSharding._active.group).item())
     R, _, na = xty(X, A, acc='f64', rows_sharded=True)
     if normalize:
         R = R / na.sqrt()[None, :]

@@ -49,14 +49,36 @@ def unpack_gram(buf, n0, n1, has_na=True, has_nb=True):
 TRI_BLOCK = 1024  # block rows of the packed upper triangle
 
 
-def _settle(t, group=None):
-    """gloo only (the CPU-side rehearsal backend; RCCL orders itself on the stream): finish this rank's queued GPU
-    work before handing a device tensor to the collective.  gloo stages device tensors through the host on streams
-    of its own; two ranks that share one GPU (tests/test_gpu_sharded.py, the bench rehearsal) otherwise wait on
-    each other's queued kernels from inside the collective, and were seen to stall there for minutes
-    (profiles/r2_gloo2_stall_stacks_before_fix.txt)."""
-    if t.is_cuda and dist.get_backend(group) != 'nccl':
-        torch.cuda.synchronize(t.device)
+def _via_host(t, group=None):
+    """gloo only (the CPU-side rehearsal backend; RCCL takes device tensors and orders itself on the stream): device
+    tensors go through the collective as host copies.  gloo's own device path stages through the host on streams of
+    its own, and two ranks that share one GPU (tests/test_gpu_sharded.py, the bench rehearsal) were seen to stall
+    inside it for minutes, waiting on each other's queued kernels (profiles/r2_gloo2_stall_stacks_before_fix.txt).
+    The .cpu() copy also finishes this rank's queued work on the tensor first."""
+    return t.is_cuda and dist.get_backend(group) != 'nccl'
+
+
+def all_reduce_sum(buf, group=None):
+    """In-place sum of `buf` over the group."""
+    if _via_host(buf, group):
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+def _all_gather(mine, group=None):
+    world = dist.get_world_size(group)
+    if _via_host(mine, group):
+        host = mine.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return [p.to(mine.device) for p in parts]
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return parts
 
 
 def pack_gram_upper(G, na=None, block=None):
@@ -95,14 +117,10 @@ def allreduce_gram(G, na=None, nb=None, group=None, symmetric=False):
         return G, na, nb
     n0, n1 = G.shape
     if symmetric and n0 == n1 and n0 > 2 * TRI_BLOCK:
-        buf = pack_gram_upper(G, na)
-        _settle(buf, group)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        buf = all_reduce_sum(pack_gram_upper(G, na), group)
         G, na = unpack_gram_upper(buf, n0, na is not None)
         return G, na, (na if nb is not None else None)
-    buf = pack_gram(G, na, nb)
-    _settle(buf, group)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf = all_reduce_sum(pack_gram(G, na, nb), group)
     return unpack_gram(buf, n0, n1, na is not None, nb is not None)
 
 
@@ -112,20 +130,14 @@ def allgather_rows(t, group=None):
     them to within one row): they are padded to the longest for the collective.  A no-op outside a group."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
-    world = dist.get_world_size(group)
-    rows = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    counts = [torch.empty_like(rows) for _ in range(world)]
-    _settle(rows, group)
-    dist.all_gather(counts, rows, group=group)
-    counts = [int(c.item()) for c in counts]
+    rows = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device if dist.get_backend(group) == 'nccl' else 'cpu')
+    counts = [int(c.item()) for c in _all_gather(rows, group)]
     longest = max(counts)
     mine = t.contiguous()
     if mine.shape[0] < longest:
         pad = torch.zeros((longest - mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
         mine = torch.cat([mine, pad], dim=0)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    _settle(mine, group)
-    dist.all_gather(parts, mine, group=group)
+    parts = _all_gather(mine, group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
@@ -135,9 +147,14 @@ def broadcast_parameters(module, src=0, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     with torch.no_grad():
+        root = dist.get_global_rank(group, src) if group is not None else src
         for t in list(module.parameters()) + list(module.buffers()):
-            _settle(t, group)
-            dist.broadcast(t.data, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+            if _via_host(t, group):
+                host = t.data.cpu()
+                dist.broadcast(host, src=root, group=group)
+                t.data.copy_(host)
+            else:
+                dist.broadcast(t.data, src=root, group=group)
 
 
 class SampleSharding:

@@ -44,7 +44,7 @@ def test_version_errors_and_argument_checks():
     assert lib.nif_xty_workspace_bytes(325000, 384, 384, 0, 0) > 0
     assert lib.nif_lap_workspace_bytes(384) > 0
     assert lib.nif_lap_workspace_bytes(100000) == 0
-    assert lib.nif_kmeans_workspace_bytes(768, 384) > 768 * 384 * 8
+    assert lib.nif_kmeans_workspace_bytes(768, 384) > 768 * 384 * 4
 
 
 def test_ops_refuse_cpu_tensors():
