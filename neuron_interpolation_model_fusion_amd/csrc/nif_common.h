@@ -105,6 +105,19 @@ void prof_begin(int slot, hipStream_t st);
 void prof_end(int slot, hipStream_t st);
 void prof_add_work(int slot, double units);  // algorithmic work of the spans of a slot (nif_profile_work)
 
+// roctx range around an entry point's host side (named after the entry point), so that rocprofv3 --marker-trace
+// groups the kernels of one call.  Off unless NIF_ROCTX=1: then the roctx library is opened on first use (no link
+// dependency); a missing library turns the ranges off again.
+struct Range {
+  explicit Range(const char* name);
+  ~Range();
+  Range(const Range&) = delete;
+  Range& operator=(const Range&) = delete;
+
+ private:
+  bool open_;
+};
+
 }  // namespace nif
 
 #endif  // NIF_COMMON_H_

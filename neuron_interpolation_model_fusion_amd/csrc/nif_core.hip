@@ -107,3 +107,44 @@ extern "C" int nif_profile_collect(int slot, double* total_ms, int64_t* launches
   *launches = cnt;
   return NIF_OK;
 }
+
+// ---- roctx ranges ---------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <stdlib.h>
+
+namespace nif {
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+roctx_push_t g_push = nullptr;
+roctx_pop_t g_pop = nullptr;
+std::once_flag g_roctx_once;
+
+void roctx_load() {
+  const char* e = getenv("NIF_ROCTX");
+  if (!e || atoi(e) == 0) return;
+  const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so",
+                         "libroctx64.so.4"};
+  for (const char* n : names) {
+    void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    g_push = reinterpret_cast<roctx_push_t>(dlsym(h, "roctxRangePushA"));
+    g_pop = reinterpret_cast<roctx_pop_t>(dlsym(h, "roctxRangePop"));
+    if (g_push && g_pop) return;
+    g_push = nullptr;
+    g_pop = nullptr;
+  }
+}
+}  // namespace
+
+Range::Range(const char* name) : open_(false) {
+  std::call_once(g_roctx_once, roctx_load);
+  if (g_push && g_pop) {
+    (void)g_push(name);
+    open_ = true;
+  }
+}
+Range::~Range() {
+  if (open_) (void)g_pop();
+}
+}  // namespace nif

@@ -55,6 +55,7 @@ __global__ void cost_hf_kernel(const double* __restrict__ G01, int64_t ldg, cons
 extern "C" int nif_cost_dist(const double* G, int64_t ldg, const double* na, const double* nb, const float* s0,
                              const float* s1, const float* colscale, int n0, int n1, float* C, int64_t ldc,
                              void* stream) {
+  nif::Range nif_range_("nif_cost_dist");
   if (!G || !na || !nb || !C || n0 <= 0 || n1 <= 0 || ldg < n1 || ldc < n1) return NIF_ERR_INVALID_ARG;
   if ((s0 == nullptr) != (s1 == nullptr)) return NIF_ERR_INVALID_ARG;
   dim3 grid((n1 + 255) / 256, n0);
@@ -67,6 +68,7 @@ extern "C" int nif_cost_dist(const double* G, int64_t ldg, const double* na, con
 extern "C" int nif_cost_hf(const double* G01, int64_t ldg, const double* pp0, const double* pp1, const double* r0,
                            const double* r1, const float* s0, const float* s1, int n0, int n1, float* C, int64_t ldc,
                            void* stream) {
+  nif::Range nif_range_("nif_cost_hf");
   if (!G01 || !pp0 || !pp1 || !r0 || !r1 || !s0 || !s1 || !C || n0 <= 0 || n1 <= 0 || ldg < n1 || ldc < n1)
     return NIF_ERR_INVALID_ARG;
   dim3 grid((n1 + 255) / 256, n0);

@@ -782,6 +782,7 @@ extern "C" size_t nif_eigh_kept_workspace_bytes(int n) {
 
 extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cutoff_rel, double* lam, double* V,
                                  int64_t ldv, int32_t* kept_host, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_eigh_kept_f64");
   using namespace nif;
   if (!G || !lam || !V || !kept_host || n <= 0 || ldg < n || !(cutoff_rel >= 0.0)) return NIF_ERR_INVALID_ARG;
   if (n > NIF_EIGH_MAX_N) return NIF_ERR_UNSUPPORTED;

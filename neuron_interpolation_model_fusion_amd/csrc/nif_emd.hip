@@ -598,6 +598,7 @@ extern "C" int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, co
                                  double tol, int flags, int32_t* colptr, int32_t* rowidx, double* val,
                                  int32_t out_cap, int32_t* status, double* u, double* v, void* ws, size_t ws_bytes,
                                  void* stream) {
+  nif::Range nif_range_("nif_emd_solve_f32");
   using namespace nif;
   if (!C || !a || !b || !colptr || !rowidx || !val || !status || n0 <= 0 || n1 <= 0 || ldc < n1 || out_cap <= 0 ||
       !(tol >= 0.0))
@@ -646,6 +647,7 @@ extern "C" int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, co
 extern "C" int nif_refit_sparse(const float* W0, const float* W1, int64_t ldw1, const int32_t* rptr, const int32_t* ri,
                                 const float* rv, const int32_t* cptr, const int32_t* ci, const float* cv, float alpha,
                                 float beta, int n_out, int n_in, int sp, float* out, void* stream) {
+  nif::Range nif_range_("nif_refit_sparse");
   using namespace nif;
   if (!W1 || !out || n_out <= 0 || n_in <= 0 || sp <= 0) return NIF_ERR_INVALID_ARG;
   if ((rptr != nullptr) != (ri != nullptr) || (rptr != nullptr) != (rv != nullptr)) return NIF_ERR_INVALID_ARG;

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(IM2ROW_NT) void im2row_kernel(Im2RowArgs a, int64_t
 
 extern "C" int nif_im2row_f32(const float* x, int64_t batch, int C, int H, int W, int kh, int kw, int sh, int sw,
                               int ph, int pw, int add_ones, float* out, int64_t ldo, void* stream) {
+  nif::Range nif_range_("nif_im2row_f32");
   using namespace nif;
   if (!x || !out || batch <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 ||
       pw < 0)

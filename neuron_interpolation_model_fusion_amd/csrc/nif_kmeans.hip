@@ -1066,37 +1066,44 @@ static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const doubl
 
 extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const double* nn, int N, int k, int first,
                                         int32_t* picks, int32_t* assign, double* mind, void* stream) {
+  nif::Range nif_range_("nif_kmeans_farthest_init");
   return nif::km_farthest_init<double>(G, ldg, nullptr, nn, N, k, first, picks, assign, mind, stream);
 }
 extern "C" int nif_kmeans_farthest_init_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, int N,
                                              int k, int first, int32_t* picks, int32_t* assign, double* mind,
                                              void* stream) {
+  nif::Range nif_range_("nif_kmeans_farthest_init_gf32");
   return nif::km_farthest_init<float>(G, ldg, gdiag, nn, N, k, first, picks, assign, mind, stream);
 }
 
 extern "C" int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn, int N, int k, int c0,
                                             int32_t* assign, void* stream) {
+  nif::Range nif_range_("nif_kmeans_assign_to_neurons");
   return nif::km_assign_to_neurons<double>(G, ldg, nullptr, nn, N, k, c0, assign, stream);
 }
 extern "C" int nif_kmeans_assign_to_neurons_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
                                                  int N, int k, int c0, int32_t* assign, void* stream) {
+  nif::Range nif_range_("nif_kmeans_assign_to_neurons_gf32");
   return nif::km_assign_to_neurons<float>(G, ldg, gdiag, nn, N, k, c0, assign, stream);
 }
 
 extern "C" int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double* nn, const float* s,
                                      const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
                                      double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_kmeans_lloyd_step");
   return nif::km_lloyd_step<double>(G, ldg, nullptr, nn, s, assign, N, k, assign_out, nearest, cost, kprime, ws, ws_bytes, stream);
 }
 extern "C" int nif_kmeans_lloyd_step_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
                                           const float* s,
                                           const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
                                           double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_kmeans_lloyd_step_gf32");
   return nif::km_lloyd_step<float>(G, ldg, gdiag, nn, s, assign, N, k, assign_out, nearest, cost, kprime, ws, ws_bytes, stream);
 }
 
 extern "C" int nif_kmeans_repair_kf(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N,
                                     int k, int32_t* changed, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_kmeans_repair_kf");
   using namespace nif;
   if (!assign || !nearest || !s || !prev || !changed || N <= 0 || k <= 0) return NIF_ERR_INVALID_ARG;
   const KmWs w = km_ws(N, k);
@@ -1113,6 +1120,7 @@ extern "C" int nif_kmeans_repair_kf(int32_t* assign, double* nearest, const floa
 extern "C" int nif_kmeans_centroid_weights(const double* W, int64_t ldw, const float* s, const int32_t* assign, int N,
                                            int k, int d, float* out, int32_t* kprime, void* ws, size_t ws_bytes,
                                            void* stream) {
+  nif::Range nif_range_("nif_kmeans_centroid_weights");
   using namespace nif;
   if (!W || !s || !assign || !out || !kprime || N <= 0 || k <= 0 || d <= 0 || ldw < N) return NIF_ERR_INVALID_ARG;
   const KmWs w = km_ws(N, k);
@@ -1131,6 +1139,7 @@ extern "C" int nif_kmeans_centroid_weights(const double* W, int64_t ldw, const f
 extern "C" int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const float* w, const int32_t* assign, int N,
                                   int k, float* T, int64_t ldt, int32_t* kprime, void* ws, size_t ws_bytes,
                                   void* stream) {
+  nif::Range nif_range_("nif_kmeans_targets");
   using namespace nif;
   if (!A || !w || !assign || !T || !kprime || m <= 0 || N <= 0 || k <= 0 || lda < N || ldt < k)
     return NIF_ERR_INVALID_ARG;

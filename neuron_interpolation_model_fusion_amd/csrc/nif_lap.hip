@@ -417,6 +417,7 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
 
 extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
                                  double* u, double* v, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_lap_solve_f32");
   using namespace nif;
   if (!C || !col4row || n <= 0 || ldc < n) return NIF_ERR_INVALID_ARG;
   if (n > NIF_LAP_MAX_N) return NIF_ERR_UNSUPPORTED;
@@ -457,6 +458,7 @@ static int lap_static_scratch(void** out) {
 
 extern "C" int nif_lap_solve_f32_static(const float* C, int64_t ldc, int n, int flags, int32_t* col4row,
                                         int32_t* row4col, double* u, double* v, void* stream) {
+  nif::Range nif_range_("nif_lap_solve_f32_static");
   using namespace nif;
   if (!C || !col4row || n <= 0 || ldc < n) return NIF_ERR_INVALID_ARG;
   if (n > NIF_LAP_STATIC_MAX_N) {
@@ -537,6 +539,7 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
 
 extern "C" int nif_lap_count_tight_f32(const float* C, int64_t ldc, int n, const int32_t* col4row, const double* u,
                                        const double* v, double tol_rel, int32_t* count, void* stream) {
+  nif::Range nif_range_("nif_lap_count_tight_f32");
   using namespace nif;
   if (!C || !col4row || !u || !v || !count || n <= 0 || ldc < n || !(tol_rel >= 0.0)) return NIF_ERR_INVALID_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

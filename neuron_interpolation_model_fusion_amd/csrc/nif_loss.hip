@@ -124,6 +124,7 @@ extern "C" size_t nif_wmse_workspace_bytes(void) { return (size_t)nif::LOSS_MAX_
 
 extern "C" int nif_wmse_forward(const float* pred, const float* truth, const float* w, int64_t outer, int C,
                                 int64_t inner, float* loss, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_wmse_forward");
   using namespace nif;
   if (!pred || !truth || !loss || outer <= 0 || C <= 0 || inner <= 0) return NIF_ERR_INVALID_ARG;
   if (!ws || ws_bytes < nif_wmse_workspace_bytes()) return NIF_ERR_WORKSPACE;
@@ -144,6 +145,7 @@ extern "C" int nif_wmse_forward(const float* pred, const float* truth, const flo
 
 extern "C" int nif_wmse_backward(const float* pred, const float* truth, const float* w, const float* grad_out,
                                  int64_t outer, int C, int64_t inner, float* grad_pred, void* stream) {
+  nif::Range nif_range_("nif_wmse_backward");
   using namespace nif;
   if (!pred || !truth || !grad_out || !grad_pred || outer <= 0 || C <= 0 || inner <= 0) return NIF_ERR_INVALID_ARG;
   const int64_t numel = outer * (int64_t)C * inner;

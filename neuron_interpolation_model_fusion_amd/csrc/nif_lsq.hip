@@ -140,6 +140,7 @@ extern "C" size_t nif_lsq_solve_workspace_bytes(int d, int N) {
 
 extern "C" int nif_lsq_solve_f64(const double* G, int64_t ldg, const double* R, int64_t ldr, int d, int N, double cutoff_rel,
                                  double* W, int64_t ldw, int32_t* rank_host, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_lsq_solve_f64");
   using namespace nif;
   if (!G || !R || !W || !rank_host || d <= 0 || N <= 0 || ldg < d || ldr < N || ldw < N || !(cutoff_rel >= 0.0))
     return NIF_ERR_INVALID_ARG;
@@ -257,6 +258,7 @@ extern "C" size_t nif_lsq_refit_workspace_bytes(int64_t m, int d, int N, int fla
 extern "C" int nif_lsq_refit_f32(const float* X, int64_t ldx, int64_t m, int d, const float* A, int64_t lda, int N, int flags,
                                  double* W, int64_t ldw, double* R, int64_t ldr, double* na, int32_t* rank_host, void* ws,
                                  size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_lsq_refit_f32");
   using namespace nif;
   if (!X || !A || !W || !R || !na || !rank_host || m <= 0 || d <= 0 || N <= 0 || ldx < d || lda < N || ldw < N || ldr < N)
     return NIF_ERR_INVALID_ARG;

@@ -66,6 +66,7 @@ __global__ void refit_pairs_kernel(const double* __restrict__ W, int64_t ldw, co
 
 extern "C" int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const float* s0, const float* s1,
                                int n0, int d, float* out, void* stream) {
+  nif::Range nif_range_("nif_refit_pairs");
   if (!W || !col || !s0 || !s1 || !out || n0 <= 0 || d <= 0 || ldw < n0) return NIF_ERR_INVALID_ARG;
   nif::clear_err();
   dim3 grid((n0 + 31) / 32, (d + 31) / 32);
@@ -77,6 +78,7 @@ extern "C" int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col,
 extern "C" int nif_refit_gather(const float* W0, const float* W1, const int32_t* rowsrc, const int32_t* colsrc,
                                 const float* alpha_v, const float* beta_v, float alpha, float beta, int n_out, int n_in,
                                 int sp, float* out, void* stream) {
+  nif::Range nif_range_("nif_refit_gather");
   if (!W1 || !out || n_out <= 0 || n_in <= 0 || sp <= 0) return NIF_ERR_INVALID_ARG;
   const int64_t width = (int64_t)n_in * sp;
   dim3 grid((unsigned)((width + 255) / 256), n_out);

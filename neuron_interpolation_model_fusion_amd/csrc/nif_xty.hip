@@ -946,6 +946,7 @@ extern "C" size_t nif_xty_workspace_bytes(int64_t m, int n0, int n1, int acc, in
 extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, int n0, int n1, int in_dtype,
                        int acc, int flags, double* G, int64_t ldg, double* na, double* nb, void* ws, size_t ws_bytes,
                        void* stream) {
+  nif::Range nif_range_("nif_xty");
   using namespace nif;
   // m == 0 (an empty shard): the operand pointers are never dereferenced and may be null
   if ((m > 0 && (!A || !B)) || !G || m < 0 || n0 <= 0 || n1 <= 0 || ldg < n1) return NIF_ERR_INVALID_ARG;
