@@ -11,6 +11,7 @@ running sum.  Non-uniform importances or unequal widths go through the exact tra
 (nif_emd_solve_f32); its plans have at most n_k + n_f - 1 entries and stay sparse, and the same
 two products become one sparse gather (nif_refit_sparse).
 """
+import os
 import time
 
 import torch
@@ -153,27 +154,32 @@ class OTFusion:
         # to fused unit j' -- or (None, SparsePlan); (None, None) = the identity coupling diag(nu_prev) of the
         # input (otfusion.py:216-217)
         # Activation mode: the ground metric of (layer, model) comes from activations captured once, so no plan depends
-        # on another one.  The assignment-shaped problems (uniform marginals, equal widths) are solved up front, side
-        # by side on their own streams (one workgroup each); the rest go through _solve_plan in the loop.
+        # on another one: all are solved up front, side by side on their own streams (one workgroup each) -- the
+        # assignment-shaped ones (uniform marginals, equal widths) by the assignment kernel, the rest by the exact
+        # transport kernel.  Weight mode goes through _solve_plan layer by layer.
         presolved = {}
-        if mode == 'acts':
-            keys, costs = [], []
+        if mode == 'acts' and os.environ.get('NIF_OTF_SERIAL_PLANS') != '1':  # (A/B aid: plans one by one in the loop)
+            keys, costs, ekeys, eprobs = [], [], [], []
             for layer in range(num_layers):
                 n_f = get_layer_width(fused_hat, layer)
                 for k, model in enumerate(self.models):
                     n_k = get_layer_width(model, layer)
-                    if n_k != n_f:
-                        continue
-                    if use_scores:
-                        mu_, nu_ = self.neuron_importance_scores[k][layer], self.target_neuron_importance_scores[layer]
-                        if not (bool(torch.equal(mu_, mu_[:1].expand_as(mu_))) and
-                                bool(torch.equal(nu_, nu_[:1].expand_as(nu_)))):
-                            continue
-                    keys.append((layer, k))
-                    costs.append(self._get_ground_metric(model, fused_hat, layer, None))
+                    mu_, nu_ = self.neuron_importance_scores[k][layer], self.target_neuron_importance_scores[layer]
+                    C = self._get_ground_metric(model, fused_hat, layer, None)
+                    if n_k == n_f and bool(torch.equal(mu_, mu_[:1].expand_as(mu_))) and \
+                            bool(torch.equal(nu_, nu_[:1].expand_as(nu_))):
+                        keys.append((layer, k))
+                        costs.append(C)
+                    else:  # the marginals _solve_plan would be handed in the loop below
+                        ekeys.append((layer, k))
+                        mu_, nu_ = mu_.to(dev), nu_.to(dev)
+                        eprobs.append((C, mu_ / mu_.sum(), nu_ / nu_.sum()))
             if costs:
                 _, rows_ = ops.lap_solve_many(costs, scipy_order=False, rows=True)
-                presolved = {key: (C, r) for key, C, r in zip(keys, costs, rows_)}
+                presolved = {key: (C, r, None) for key, C, r in zip(keys, costs, rows_)}
+            if eprobs:
+                plans_ = ops.emd_solve_many(eprobs)
+                presolved.update({key: (pr[0], None, plan) for key, pr, plan in zip(ekeys, eprobs, plans_)})
         prev_plan = [(None, None) for _ in self.models]
         prev_width = [input_dim for _ in self.models]
         nu_prev = None
@@ -232,7 +238,7 @@ class OTFusion:
                     else:
                         edges = ops.refit_sparse(None, wk_flat, cols=cols, sp=sp)
                     C = self._get_ground_metric(model, fused_hat, layer, edges)
-                perm, sparse = (presolved[(layer, k)][1], None) if (layer, k) in presolved else _solve_plan(C, mu, nu)
+                perm, sparse = presolved[(layer, k)][1:] if (layer, k) in presolved else _solve_plan(C, mu, nu)
                 self.plans.append((layer, k, perm if sparse is None else sparse))
                 last = layer == num_layers - 1  # T_corrected = I on the output layer (otfusion.py:315-316)
                 if handle_bias:

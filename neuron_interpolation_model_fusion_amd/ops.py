@@ -682,9 +682,8 @@ class SparsePlan:
         return self.colptr, self.rowidx, v.float().contiguous()
 
 
-def emd_solve(C, a, b, duals=False):
-    """Exact optimal transport plan for cost C (n0 x n1 f32, >= 0) and marginals a, b (``ot.emd(a, b, C)``,
-    otfusion.py:32).  b is rescaled to a's total like POT does.  Returns a SparsePlan (and f64 duals u, v)."""
+def _emd_problem(C, a, b):
+    """Checked inputs and output buffers of one transport problem."""
     _need_gpu(C, a, b)
     C = _mat(C.float(), 'C')
     n0, n1 = C.shape
@@ -694,33 +693,75 @@ def emd_solve(C, a, b, duals=False):
     b = (b * (a.sum() / b.sum())).contiguous()
     if a.numel() != n0 or b.numel() != n1:
         raise ValueError(f'marginals {a.numel()}, {b.numel()} do not match the cost {n0} x {n1}')
-    tol = 1e-13 * float(a.sum())
     with torch.cuda.device(dev):
         cap = n0 + n1 + 64
-        colptr = torch.empty(n1 + 1, dtype=torch.int32, device=dev)
-        rowidx = torch.empty(cap, dtype=torch.int32, device=dev)
-        val = torch.empty(cap, dtype=torch.float64, device=dev)
-        status = torch.zeros(4, dtype=torch.int32, device=dev)
-        u = torch.empty(n0, dtype=torch.float64, device=dev)
-        v = torch.empty(n1, dtype=torch.float64, device=dev)
         wsz = lib.nif_emd_workspace_bytes(n0, n1)
         if wsz == 0:
             raise _lib.NifError(f'nif_emd_solve_f32: sizes {n0} x {n1} beyond NIF_EMD_MAX_N')
-        ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
-        for flags in (0, _lib.NIF_EMD_EDGES_GLOBAL):
-            check(lib.nif_emd_solve_f32(_ptr(C), _ld(C), n0, n1, _ptr(a), _ptr(b), tol, flags, _ptr(colptr),
-                                        _ptr(rowidx), _ptr(val), cap, _ptr(status), _ptr(u), _ptr(v), _ptr(ws), wsz,
-                                        _stream()), 'nif_emd_solve_f32')
-            work = status.tolist()
-            if work[0] != _lib.NIF_ERR_WORKSPACE:  # a degenerate problem outgrew the LDS arc pool: retry once
-                break
-        status = work
-        nnz = status[0]
-    emd_solve.last_work = dict(augmentations=status[1], steps=status[2], rows_expanded=status[3])
+        return dict(C=C, a=a, b=b, n0=n0, n1=n1, dev=dev, cap=cap, wsz=wsz, tol=a.sum() * 1e-13,
+                    colptr=torch.empty(n1 + 1, dtype=torch.int32, device=dev),
+                    rowidx=torch.empty(cap, dtype=torch.int32, device=dev),
+                    val=torch.empty(cap, dtype=torch.float64, device=dev),
+                    status=torch.zeros(4, dtype=torch.int32, device=dev),
+                    u=torch.empty(n0, dtype=torch.float64, device=dev),
+                    v=torch.empty(n1, dtype=torch.float64, device=dev),
+                    ws=torch.empty(wsz, dtype=torch.uint8, device=dev))
+
+
+def _emd_launch(p, flags, stream):
+    check(lib.nif_emd_solve_f32(_ptr(p['C']), _ld(p['C']), p['n0'], p['n1'], _ptr(p['a']), _ptr(p['b']), p['tol'], flags,
+                                _ptr(p['colptr']), _ptr(p['rowidx']), _ptr(p['val']), p['cap'], _ptr(p['status']),
+                                _ptr(p['u']), _ptr(p['v']), _ptr(p['ws']), p['wsz'], stream), 'nif_emd_solve_f32')
+
+
+def _emd_result(p, work, duals):
+    nnz = work[0]
     if nnz < 0:
         check(nnz, 'nif_emd_solve_f32 (device status)')
-    plan = SparsePlan(n0, n1, colptr, rowidx[:nnz].contiguous(), val[:nnz].contiguous())
-    return (plan, u, v) if duals else plan
+    plan = SparsePlan(p['n0'], p['n1'], p['colptr'], p['rowidx'][:nnz].contiguous(), p['val'][:nnz].contiguous())
+    return (plan, p['u'], p['v']) if duals else plan
+
+
+def emd_solve(C, a, b, duals=False):
+    """Exact optimal transport plan for cost C (n0 x n1 f32, >= 0) and marginals a, b (``ot.emd(a, b, C)``,
+    otfusion.py:32).  b is rescaled to a's total like POT does.  Returns a SparsePlan (and f64 duals u, v)."""
+    p = _emd_problem(C, a, b)
+    p['tol'] = float(p['tol'])
+    with torch.cuda.device(p['dev']):
+        for flags in (0, _lib.NIF_EMD_EDGES_GLOBAL):
+            _emd_launch(p, flags, _stream())
+            work = p['status'].tolist()
+            if work[0] != _lib.NIF_ERR_WORKSPACE:  # a degenerate problem outgrew the LDS arc pool: retry once
+                break
+    emd_solve.last_work = dict(augmentations=work[1], steps=work[2], rows_expanded=work[3])
+    return _emd_result(p, work, duals)
+
+
+def emd_solve_many(problems, duals=False):
+    """emd_solve for independent problems [(C, a, b), ...], side by side: the solver is one workgroup per problem,
+    so every problem runs on a stream of its own and the statuses are read back once.  Same plans as one by one."""
+    if not problems:
+        return []
+    ps = [_emd_problem(C, a, b) for C, a, b in problems]
+    dev = ps[0]['dev']
+    tols = torch.stack([p['tol'] for p in ps]).tolist()  # one read-back for every tolerance
+    main = torch.cuda.current_stream(dev)
+    with torch.cuda.device(dev):
+        streams = [torch.cuda.Stream(dev) for _ in ps]
+        for p, tol, st in zip(ps, tols, streams):
+            p['tol'] = tol
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                _emd_launch(p, 0, st.cuda_stream)
+        for st in streams:
+            main.wait_stream(st)
+        works = torch.stack([p['status'] for p in ps]).tolist()
+        for i, (p, work) in enumerate(zip(ps, works)):
+            if work[0] == _lib.NIF_ERR_WORKSPACE:  # outgrew the LDS arc pool: once more with the pool in global memory
+                _emd_launch(p, _lib.NIF_EMD_EDGES_GLOBAL, _stream())
+                works[i] = p['status'].tolist()
+    emd_solve_many.last_work = [dict(augmentations=w[1], steps=w[2], rows_expanded=w[3]) for w in works]
+    return [_emd_result(p, w, duals) for p, w in zip(ps, works)]
 
 
 def refit_sparse(W0, W1, rows=None, cols=None, alpha=1.0, beta=1.0, sp=1):

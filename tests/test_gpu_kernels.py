@@ -345,6 +345,22 @@ def test_emd_plan_matches_the_lp_oracle(ops, n0, n1):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=3e-7, rtol=1e-4)  # HiGHS' own feasibility tolerance is 1e-7
 
 
+def test_emd_solve_many_equals_one_by_one(ops):
+    """Independent transport problems solved side by side (one stream each) give the plans of emd_solve."""
+    g = torch.Generator().manual_seed(5)
+    probs = []
+    for n0, n1 in [(17, 17), (40, 33), (64, 64), (25, 90), (128, 128)]:
+        C = torch.rand(n0, n1, generator=g).cuda()
+        a = (torch.rand(n0, generator=g) + 0.1).double()
+        b = (torch.rand(n1, generator=g) + 0.1).double()
+        probs.append((C, (a / a.sum()).cuda(), (b / b.sum()).cuda()))
+    many = ops.emd_solve_many(probs, duals=True)
+    for (C, a, b), (plan, u, v) in zip(probs, many):
+        one, u1, v1 = ops.emd_solve(C, a, b, duals=True)
+        assert torch.equal(plan.colptr, one.colptr) and torch.equal(plan.rowidx, one.rowidx)
+        assert torch.equal(plan.val, one.val) and torch.equal(u, u1) and torch.equal(v, v1)
+
+
 def test_emd_degenerate_and_uniform_cases(ops):
     """Ties / degenerate vertices: the plan need not be unique, the optimal value is."""
     g = torch.Generator().manual_seed(5)

@@ -19,6 +19,7 @@ ap.add_argument('--models', type=int, default=2)
 ap.add_argument('--batch', type=int, default=400)
 ap.add_argument('--vgg', default='VGG11')
 ap.add_argument('--verbose', action='store_true')
+ap.add_argument('--importance', default='uniform', help='OTFusion neuron importance: uniform | conductance | deeplift')
 ap.add_argument('--planted', action='store_true', help='model k = noisy copy of model 0 with permuted hidden units '
                                                          '(what trained models look like to the matcher) instead of '
                                                          'independent random initialisations')
@@ -64,8 +65,10 @@ for rep in range(2):
         elif a.algo == 'gr':
             fused = GitRebasin(models[0], models[1]).fuse(X, None, 'uniform')
         else:
-            st = {'mode': 'acts', 'acts': {'activations_dataset': X, 'activation_labels': None,
-                                           'neuron_importance_method': 'uniform', 'normalize_activations': False}}
+            y = None if a.importance == 'uniform' else (torch.arange(a.batch, device=dev) % 10)
+            st = {'mode': 'acts', 'acts': {'activations_dataset': X, 'activation_labels': y,
+                                           'neuron_importance_method': a.importance, 'normalize_activations': False,
+                                           'rescale_min_importance': 0.2}}
             fused = OTFusion(models[:-1], models[-1]).fuse_models(st)
     torch.cuda.synchronize()
     dt = time.time() - t0
