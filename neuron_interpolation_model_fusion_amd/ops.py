@@ -446,15 +446,25 @@ def ls_solve(X, A, normalize=False):
                                         _ptr(na), ctypes.byref(rank), _ptr(ws), nbytes, _stream()), 'nif_lsq_refit_f32')
         return dict(W=W, R=R, na=na, rank=rank.value)
     # sample-sharded: m is the GLOBAL row count for pinv's cutoff, and the dual form would need every row locally,
-    # so the d x d normal equations are reduced and solved on every rank (identical inputs -> identical results)
-    import torch.distributed as dist
-    from .parallel import all_reduce_sum
-    m = int(all_reduce_sum(torch.tensor([m], device=X.device, dtype=torch.int64), SampleSharding._active.group).item())
-    R, _, na = xty(X, A, acc='f64', rows_sharded=True)
+    # so the d x d normal equations are reduced and solved on every rank (identical inputs -> identical results).
+    # ONE collective per layer: [G (block upper triangle when large) | R | na | m] travel as one f64 buffer.
+    from . import parallel
+    group = SampleSharding._active.group
+    R, _, na = xty(X, A, acc='f64')  # this rank's partial products (no rows_sharded: they are reduced together below)
+    G, _, _ = xty(X, None, acc='f64', norms=False)
+    tri = d > 2 * parallel.TRI_BLOCK
+    gpart = parallel.pack_gram_upper(G) if tri else G.reshape(-1).double()
+    buf = torch.cat([gpart, R.reshape(-1).double(), na.double(),
+                     torch.tensor([float(m)], dtype=torch.float64, device=X.device)])
+    parallel.all_reduce_sum(buf, group)
+    ng = gpart.numel()
+    G = parallel.unpack_gram_upper(buf[:ng], d, has_na=False)[0] if tri else buf[:ng].view(d, d)
+    R = buf[ng:ng + d * N].view(d, N)
+    na = buf[ng + d * N:ng + d * N + N]
+    m = int(round(float(buf[-1].item())))
     if normalize:
         R = R / na.sqrt()[None, :]
         na = torch.ones_like(na)
-    G, _, _ = xty(X, None, acc='f64', norms=False, rows_sharded=True)
     G, R = G.contiguous(), R.contiguous()
     rtol = max(m, d) * _EPS32
     with torch.cuda.device(X.device):
