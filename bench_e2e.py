@@ -124,7 +124,7 @@ def run_c3(ops, device, steps, warmup, hidden=8192, batch=4096):
         workload=f'C3 Git Re-Basin of two MLPs 784-{hidden}-10, {batch} samples, planted hidden-unit permutation: '
                  f'{hidden} x {hidden} activation Gram + assignment + refit; whole GitRebasin.fuse() wall-clock',
         extra={'seconds_each': [round(t, 4) for t in times], 'planted_permutation_recovered': ok,
-               'assignment_path': ops.lap_solve.last_path, 'levels_per_fusion': 2,
+               'assignment_paths': list(getattr(ops.lap_solve_many, 'last_paths', [])), 'levels_per_fusion': 2,
                'levels_per_s': 2 / float(np.mean(times))},
         roofline={'kernel': 'nif::xty_kernel<float, MmaF32> (v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
                   'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

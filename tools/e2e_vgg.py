@@ -67,8 +67,9 @@ for rep in range(2):
         else:
             y = None if a.importance == 'uniform' else (torch.arange(a.batch, device=dev) % 10)
             st = {'mode': 'acts', 'acts': {'activations_dataset': X, 'activation_labels': y,
-                                           'neuron_importance_method': a.importance, 'normalize_activations': False,
-                                           'rescale_min_importance': 0.2}}
+                                           'neuron_importance_method': a.importance, 'normalize_activations': False}}
+            if a.importance != 'uniform':  # (rescaling constant scores divides 0 by 0, in the reference too)
+                st['acts']['rescale_min_importance'] = 0.2
             fused = OTFusion(models[:-1], models[-1]).fuse_models(st)
     torch.cuda.synchronize()
     dt = time.time() - t0
