@@ -71,6 +71,25 @@ class BaseModel(nn.Module, ABC):
         self.train_indices = train_indices
         self.val_indices = val_indices
 
+    def _adopt_weights(self, twin):
+        """What `twin.load_state_dict(self.state_dict()); twin.to(self.device)` leaves behind (models/vgg.py:120-125,
+        mlp.py, vit.py copy_model), without its two trips over PCIe: the freshly built twin lives on the host, so the
+        reference's sequence copies every weight device -> host (synchronising) and back.  Here every parameter and
+        buffer of the twin is re-pointed at a device clone of ours."""
+        mine = dict(self.named_parameters())
+        mine.update(dict(self.named_buffers()))
+        theirs = dict(twin.named_parameters())
+        theirs.update(dict(twin.named_buffers()))
+        if mine.keys() != theirs.keys():
+            raise RuntimeError(f'copy_model: state mismatch {sorted(mine.keys() ^ theirs.keys())}')
+        with torch.no_grad():
+            for name, t in theirs.items():
+                src = mine[name]
+                if src.shape != t.shape:
+                    raise RuntimeError(f'copy_model: size mismatch for {name}: {tuple(src.shape)} vs {tuple(t.shape)}')
+                t.data = src.detach().clone()
+        return twin.to(self.device)  # anything that is not a parameter or buffer follows; a no-op otherwise
+
     # -- structure ---------------------------------------------------------------
     @property
     @abstractmethod

@@ -37,8 +37,7 @@ class MLPNet(BaseModel):
     def copy_model(self):
         twin = MLPNet(self.input_size, self.hidden_size, self.output_size, self.use_bias, self.use_activations,
                       self.train_indices, self.val_indices)
-        twin.load_state_dict(self.state_dict())
-        return twin.to(self.device)
+        return self._adopt_weights(twin)
 
     @property
     def get_ordered_trainable_named_layers(self):

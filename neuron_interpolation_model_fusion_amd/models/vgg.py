@@ -94,8 +94,7 @@ class VGG(BaseModel):
     def copy_model(self):
         twin = VGG(self.vgg_name, self.num_classes, self.input_shape, batch_norm=self.use_batch_norm,
                    use_bias=self.use_bias, use_activations=self.use_activations)
-        twin.load_state_dict(self.state_dict())
-        return twin.to(self.device)
+        return self._adopt_weights(twin)
 
     @property
     def get_ordered_trainable_named_layers(self):

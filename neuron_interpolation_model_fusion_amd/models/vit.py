@@ -111,8 +111,7 @@ class ViT(BaseModel):
         twin = ViT(in_c=self.in_c, num_classes=self.num_classes, img_size=self.img_size, patch=self.patch,
                    dropout=self.dropout_p, depth=self.depth, hidden=self.hidden, mlp_hidden=self.mlp_hidden,
                    head=self.head, embedder_separare_level=self.embedder_separare_level)
-        twin.load_state_dict(self.state_dict())
-        return twin.to(self.device)
+        return self._adopt_weights(twin)
 
     @property
     def get_ordered_trainable_named_layers(self):
