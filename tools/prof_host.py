@@ -7,7 +7,7 @@ from neuron_interpolation_model_fusion_amd.models.base_model import twin_copy
 twin_copy.replay_init_draws = False
 dev = torch.device('cuda')
 models = []
-for k in range(2):
+for k in range(4):
     torch.manual_seed(100 + k)
     models.append(VGG('VGG11', 10, (3, 32, 32), batch_norm=False, use_bias=True, use_activations=False).eval().to(dev))
 torch.manual_seed(0); np.random.seed(0)
@@ -17,6 +17,8 @@ def run():
     with contextlib.redirect_stdout(io.StringIO()):
         if algo == 'gr':
             GitRebasin(models[0], models[1]).fuse(X, None, 'uniform')
+        elif algo == 'kf':
+            LSFusion(models).fuse(X, None, 'k_means')
         else:
             LSFusion(models[:2]).fuse(X, None, 'hungarian')
     torch.cuda.synchronize()
