@@ -216,6 +216,14 @@ int nif_kmeans_farthest_init(const double* G, int64_t ldg, const double* nn, int
                              int32_t* picks, int32_t* assign, double* mind, void* stream);
 int nif_kmeans_farthest_init_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, int N, int k,
                                   int first, int32_t* picks, int32_t* assign, double* mind, void* stream);
+/* The `tries` (<= 16) initialisations of one layer (hf_kf.py:420-441: same matrices, a different first neuron per
+ * try) in ONE launch: firsts is a HOST array; picks [tries][k], assign [tries][N], mind [tries][N]. */
+int nif_kmeans_farthest_init_batch(const double* G, int64_t ldg, const double* nn, int N, int k,
+                                   const int32_t* firsts, int tries, int32_t* picks, int32_t* assign, double* mind,
+                                   void* stream);
+int nif_kmeans_farthest_init_batch_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, int N,
+                                        int k, const int32_t* firsts, int tries, int32_t* picks, int32_t* assign,
+                                        double* mind, void* stream);
 
 /* ALF initial assignment, alf.py:221-229: centroids are neurons c0 .. c0+k-1. */
 int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn, int N, int k, int c0,

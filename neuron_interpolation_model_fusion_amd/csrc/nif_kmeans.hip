@@ -56,6 +56,13 @@ __device__ __forceinline__ void block_argmax(double& v, int& j, double* sv, int*
   }
 }
 
+// Up to 16 initialisations (KF's tries: same G, different first neuron) ride in one launch: blockIdx.y is the try,
+// its outputs are rows of [tries][k] picks and [tries][N] assign / mind.
+constexpr int FI_MAX_TRIES = 16;
+struct FiFirsts {
+  int first[FI_MAX_TRIES];
+};
+
 // ---- farthest-point initialisation (hf_kf.py:424-441), one workgroup ----------------------------
 // picks[0] = first; picks[c] = argmax_j min_{c' < c} dist(centroid c', neuron j), where centroid c'
 // is the PROJECTED neuron picks[c'] and dist^2 = G[p][p] - 2 G[p][j] + nn[j].  Also leaves the
@@ -63,12 +70,15 @@ __device__ __forceinline__ void block_argmax(double& v, int& j, double* sv, int*
 template <typename GT>
 __global__ __launch_bounds__(1024) void kmeans_farthest_init_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                                                     const double* __restrict__ nn, int N, int k,
-                                                                    int first, int* __restrict__ picks,
+                                                                    FiFirsts fb, int* __restrict__ picks,
                                                                     int* __restrict__ assign,
                                                                     double* __restrict__ mind) {
   __shared__ double sv[16];
   __shared__ int sj[16];
-  int idx = first;
+  picks += (size_t)blockIdx.y * k;
+  assign += (size_t)blockIdx.y * N;
+  mind += (size_t)blockIdx.y * N;
+  int idx = fb.first[blockIdx.y];
   for (int c = 0; c < k; ++c) {
     if (threadIdx.x == 0) picks[c] = idx;
     const GT* __restrict__ row = G + (int64_t)idx * ldg;
@@ -105,11 +115,15 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_kernel(const GT* __
 template <int EPT, typename GT>
 __global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                                                         const double* __restrict__ nn, int N, int k,
-                                                                        int first, int* __restrict__ picks,
+                                                                        FiFirsts fb, int* __restrict__ picks,
                                                                         int* __restrict__ assign,
                                                                         double* __restrict__ mind) {
   __shared__ double sv[16];
   __shared__ int sj[16];
+  picks += (size_t)blockIdx.y * k;
+  assign += (size_t)blockIdx.y * N;
+  mind += (size_t)blockIdx.y * N;
+  const int first = fb.first[blockIdx.y];
   double md[EPT], nj[EPT];
   int lab[EPT];
 #pragma unroll
@@ -174,7 +188,7 @@ static __device__ __align__(256) unsigned long long fi_mailbox[FI_REGIONS * FI_R
 template <int EPT, typename GT>
 __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                                                           const double* __restrict__ nn, int N, int k,
-                                                                          int first, int span, int* __restrict__ picks,
+                                                                          FiFirsts fb, int span, int* __restrict__ picks,
                                                                           int* __restrict__ assign,
                                                                           double* __restrict__ mind,
                                                                           unsigned long long* mbox) {
@@ -182,6 +196,11 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const 
   __shared__ double sv[16];
   __shared__ int sj[16];
   __shared__ int s_next;
+  picks += (size_t)blockIdx.y * k;
+  assign += (size_t)blockIdx.y * N;
+  mind += (size_t)blockIdx.y * N;
+  mbox += (size_t)blockIdx.y * FI_REGION_WORDS;  // every try has a mailbox region of its own
+  const int first = fb.first[blockIdx.y];
   const int B = gridDim.x, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int j0 = b * span;
   double md[EPT], nj[EPT];
@@ -960,16 +979,22 @@ extern "C" size_t nif_kmeans_workspace_bytes(int N, int k) {
 namespace nif {
 
 template <typename GT>
-static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const double* nn, int N, int k, int first, int32_t* picks,
-                            int32_t* assign, double* mind, void* stream) {
-  if (!G || !nn || !picks || !assign || !mind || N <= 0 || k <= 0 || ldg < N || first < 0 || first >= N ||
-      (sizeof(GT) == 4 && !gd))
+static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const double* nn, int N, int k,
+                            const int32_t* firsts, int tries, int32_t* picks, int32_t* assign, double* mind,
+                            void* stream) {
+  if (!G || !nn || !firsts || !picks || !assign || !mind || N <= 0 || k <= 0 || ldg < N || tries < 1 ||
+      tries > FI_MAX_TRIES || (sizeof(GT) == 4 && !gd))
     return NIF_ERR_INVALID_ARG;
+  FiFirsts fb;
+  for (int t = 0; t < FI_MAX_TRIES; ++t) {
+    fb.first[t] = t < tries ? firsts[t] : 0;
+    if (fb.first[t] < 0 || fb.first[t] >= N) return NIF_ERR_INVALID_ARG;
+  }
   clear_err();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int fi_single = env_int("NIF_KMEANS_INIT_SINGLE_WG");  // tuning aid: keep the one-workgroup kernel
   if (N > 4096 && N <= FI_MAX_WG * 4096 && !fi_single) {
-    // several workgroups, one mailbox exchange per pick (see kmeans_farthest_init_multi_kernel)
+    // several workgroups per try, one mailbox exchange per pick (see kmeans_farthest_init_multi_kernel)
     static std::mutex mu;
     static unsigned long long* base[64];
     static unsigned seq = 0;
@@ -983,16 +1008,20 @@ static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const do
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(fi_mailbox)) != hipSuccess || !p) return NIF_ERR_NO_DEVICE;
         base[dev] = reinterpret_cast<unsigned long long*>(p);
       }
-      region = base[dev] + (size_t)(seq++ % FI_REGIONS) * FI_REGION_WORDS;
+      unsigned r0 = seq % FI_REGIONS;  // `tries` consecutive regions, never wrapping
+      if (r0 + (unsigned)tries > (unsigned)FI_REGIONS) r0 = 0;
+      seq = r0 + (unsigned)tries;
+      region = base[dev] + (size_t)r0 * FI_REGION_WORDS;
     }
     int B = (N + 2047) / 2048;            // two neurons per lane where that fills <= 16 workgroups
     if (B > FI_MAX_WG) B = FI_MAX_WG;
     const int span = (N + B - 1) / B;
     const int ept = (span + 1023) / 1024;
-    if (hipMemsetAsync(region, 0, FI_REGION_WORDS * sizeof(unsigned long long), st) != hipSuccess) return NIF_ERR_LAUNCH;
-#define NIF_FIM_GO(E)                                                                                                 \
-  hipLaunchKernelGGL((kmeans_farthest_init_multi_kernel<E, GT>), dim3(B), dim3(1024), 0, st, G, ldg, gd, nn, N, k,   \
-                     first, span, picks, assign, mind, region)
+    if (hipMemsetAsync(region, 0, (size_t)tries * FI_REGION_WORDS * sizeof(unsigned long long), st) != hipSuccess)
+      return NIF_ERR_LAUNCH;
+#define NIF_FIM_GO(E)                                                                                                  \
+  hipLaunchKernelGGL((kmeans_farthest_init_multi_kernel<E, GT>), dim3(B, tries), dim3(1024), 0, st, G, ldg, gd, nn, N, \
+                     k, fb, span, picks, assign, mind, region)
     if (ept <= 1) NIF_FIM_GO(1);
     else if (ept <= 2) NIF_FIM_GO(2);
     else NIF_FIM_GO(4);
@@ -1001,8 +1030,8 @@ static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const do
   }
   const int ept = (N + 1023) / 1024;
 #define NIF_FI_GO(E)                                                                                                   \
-  hipLaunchKernelGGL((kmeans_farthest_init_reg_kernel<E, GT>), dim3(1), dim3(1024), 0, st, G, ldg, gd, nn, N, k, first, \
-                     picks, assign, mind)
+  hipLaunchKernelGGL((kmeans_farthest_init_reg_kernel<E, GT>), dim3(1, tries), dim3(1024), 0, st, G, ldg, gd, nn, N, k, \
+                     fb, picks, assign, mind)
   if (ept <= 1) NIF_FI_GO(1);
   else if (ept <= 2) NIF_FI_GO(2);
   else if (ept <= 4) NIF_FI_GO(4);
@@ -1010,7 +1039,7 @@ static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const do
   else if (ept <= 16) NIF_FI_GO(16);
   else if (ept <= 32) NIF_FI_GO(32);
   else
-    hipLaunchKernelGGL(kmeans_farthest_init_kernel<GT>, dim3(1), dim3(1024), 0, st, G, ldg, gd, nn, N, k, first, picks,
+    hipLaunchKernelGGL(kmeans_farthest_init_kernel<GT>, dim3(1, tries), dim3(1024), 0, st, G, ldg, gd, nn, N, k, fb, picks,
                        assign, mind);
 #undef NIF_FI_GO
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
@@ -1067,13 +1096,25 @@ static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const doubl
 extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const double* nn, int N, int k, int first,
                                         int32_t* picks, int32_t* assign, double* mind, void* stream) {
   nif::Range nif_range_("nif_kmeans_farthest_init");
-  return nif::km_farthest_init<double>(G, ldg, nullptr, nn, N, k, first, picks, assign, mind, stream);
+  return nif::km_farthest_init<double>(G, ldg, nullptr, nn, N, k, &first, 1, picks, assign, mind, stream);
+}
+extern "C" int nif_kmeans_farthest_init_batch(const double* G, int64_t ldg, const double* nn, int N, int k,
+                                              const int32_t* firsts, int tries, int32_t* picks, int32_t* assign,
+                                              double* mind, void* stream) {
+  nif::Range nif_range_("nif_kmeans_farthest_init_batch");
+  return nif::km_farthest_init<double>(G, ldg, nullptr, nn, N, k, firsts, tries, picks, assign, mind, stream);
 }
 extern "C" int nif_kmeans_farthest_init_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, int N,
                                              int k, int first, int32_t* picks, int32_t* assign, double* mind,
                                              void* stream) {
   nif::Range nif_range_("nif_kmeans_farthest_init_gf32");
-  return nif::km_farthest_init<float>(G, ldg, gdiag, nn, N, k, first, picks, assign, mind, stream);
+  return nif::km_farthest_init<float>(G, ldg, gdiag, nn, N, k, &first, 1, picks, assign, mind, stream);
+}
+extern "C" int nif_kmeans_farthest_init_batch_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
+                                                   int N, int k, const int32_t* firsts, int tries, int32_t* picks,
+                                                   int32_t* assign, double* mind, void* stream) {
+  nif::Range nif_range_("nif_kmeans_farthest_init_batch_gf32");
+  return nif::km_farthest_init<float>(G, ldg, gdiag, nn, N, k, firsts, tries, picks, assign, mind, stream);
 }
 
 extern "C" int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn, int N, int k, int c0,

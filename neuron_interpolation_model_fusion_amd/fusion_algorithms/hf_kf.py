@@ -169,21 +169,15 @@ class LSFusion:
             # reference's loop (and a try-by-try port) synchronises twice per step.  Each try keeps the exact
             # control flow of hf_kf.py:448-475; the first-centroid draws come from np.random in try order.
             t0 = time.time()
+            # the farthest-point passes of all tries (same matrices, another first neuron each) are ONE launch: a try is
+            # one workgroup (or one row of workgroups), so they run side by side
+            firsts = [int(np.random.randint(low=0, high=output_size)) for _ in range(num_k_means_tries)]  # (:424)
             tries = []
-            main_stream = torch.cuda.current_stream(dev)
-            for t in range(num_k_means_tries):
-                first = int(np.random.randint(low=0, high=output_size))  # a neuron of model 0 (:424)
-                solver = km if t == 0 else ops.KMeans(GP, na, s, output_size, gdiag=gdiag)  # own workspace per try
-                # the farthest-point pass is one workgroup walking k picks: the tries run side by side on their
-                # own streams (one CU each) instead of queueing behind each other
-                side = torch.cuda.Stream(dev)
-                side.wait_stream(main_stream)
-                with torch.cuda.stream(side):
-                    _, assignment = solver.farthest_init(first)
-                assignment.record_stream(main_stream)
-                tries.append(dict(km=solver, assignment=assignment, costs=[], live=True, stream=side))
-            for tr in tries:
-                main_stream.wait_stream(tr['stream'])
+            for lo in range(0, num_k_means_tries, 16):
+                _, assignments = km.farthest_init_many(firsts[lo:lo + 16])
+                for t in range(assignments.shape[0]):
+                    solver = km if lo + t == 0 else ops.KMeans(GP, na, s, output_size, gdiag=gdiag)  # own workspace per try
+                    tries.append(dict(km=solver, assignment=assignments[t], costs=[], live=True))
             it_init = num_k_means_tries * (output_size - 1)
             torch.cuda.synchronize(dev)
             t_init = time.time() - t0

@@ -544,6 +544,20 @@ class KMeans:
                      _ptr(assign), _ptr(self.mind), _stream()), 'nif_kmeans_farthest_init' + self._sfx)
         return picks, assign
 
+    def farthest_init_many(self, firsts):
+        """farthest_init for several first neurons (KF's tries) in one launch: (picks [T, k], assign [T, N])."""
+        firsts = [int(f) for f in firsts]
+        T = len(firsts)
+        arr = (ctypes.c_int32 * T)(*firsts)
+        with torch.cuda.device(self.dev):
+            picks = torch.empty((T, self.k), dtype=torch.int32, device=self.dev)
+            assign = torch.empty((T, self.N), dtype=torch.int32, device=self.dev)
+            mind = torch.empty((T, self.N), dtype=torch.float64, device=self.dev)
+            fn = getattr(lib, 'nif_kmeans_farthest_init_batch' + self._sfx)
+            check(fn(_ptr(self.G), self.G.stride(0), *self._g, _ptr(self.nn), self.N, self.k, arr, T, _ptr(picks),
+                     _ptr(assign), _ptr(mind), _stream()), 'nif_kmeans_farthest_init_batch' + self._sfx)
+        return picks, assign
+
     def assign_to_neurons(self, c0):
         with torch.cuda.device(self.dev):
             assign = self._i32(self.N)

@@ -558,6 +558,22 @@ def test_kmeans_farthest_init_matches_sequential_reference(ops, N, k, gdtype):
     np.testing.assert_allclose(km.mind.cpu().numpy(), mind.numpy(), rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize('gdtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('N,k,T', [(300, 20, 10), (3000, 33, 16), (6000, 40, 10), (24576, 12, 3)])
+def test_kmeans_farthest_init_many_equals_one_by_one(ops, N, k, T, gdtype):
+    """The tries of one KF layer in one launch (one workgroup, or one row of workgroups, per try)."""
+    g = torch.Generator().manual_seed(N + T)
+    A = torch.randn(24, N, generator=g).double()
+    G = ((0.9 * A).T @ (0.9 * A)).to(gdtype).cuda()
+    nn = (A * A).sum(0).cuda()
+    km = ops.KMeans(G, nn, torch.ones(N).cuda(), k)
+    firsts = torch.randint(0, N, (T,), generator=g).tolist()
+    picks, assign = km.farthest_init_many(firsts)
+    for t, first in enumerate(firsts):
+        p1, a1 = km.farthest_init(first)
+        assert torch.equal(picks[t], p1) and torch.equal(assign[t], a1), (t, first)
+
+
 def test_kmeans_centroid_weights_and_repair(ops):
     N, k, d = 40, 9, 17
     g = torch.Generator().manual_seed(2)
