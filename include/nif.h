@@ -281,6 +281,20 @@ int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, const double*
                       int flags, int32_t* colptr, int32_t* rowidx, double* val, int32_t out_cap, int32_t* status,
                       double* u, double* v, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- entropic optimal transport (Sinkhorn-Knopp): an ADDITIONAL, approximate plan solver -------------------
+ * No counterpart in the reference, which calls the exact ot.emd (otfusion.py:18-32, :309); north_star (2) / SURVEY D1
+ * ask for it as a documented-approximate mode with its own HBM roofline.  Restates POT's `ot.sinkhorn(a, b, M, reg)`
+ * (method 'sinkhorn': K = exp(-M / reg), v = b / K^T u, u = a / K v, every 10th iteration the marginal error
+ * ||v * K^T u - b||_2 against tol, at most max_iter iterations; T = diag(u) K diag(v)).  C: n0 x n1 f32; a, b f64;
+ * T: n0 x n1 f32 (ldt); u / v (optional, f64): the scalings; info (device, 2 ints): [0] = 0 iteration cap reached,
+ * 1 converged, 2 numerical breakdown (a zero or non-finite sum: the last good u, v are returned, as POT does),
+ * [1] = iterations completed; err (device f64): the last marginal error evaluated.  HBM-bound: 8 n0 n1 bytes per
+ * iteration (K streamed twice).  Synchronises the stream once per 50 iterations to read the state word. */
+size_t nif_sinkhorn_workspace_bytes(int n0, int n1);
+int nif_sinkhorn_f32(const float* C, int64_t ldc, int n0, int n1, const double* a, const double* b, double reg,
+                     int max_iter, double tol, float* T, int64_t ldt, double* u, double* v, int32_t* info, double* err,
+                     void* ws, size_t ws_bytes, void* stream);
+
 /* OTFusion alignment with general (sparse) plans, otfusion.py:261-335:
  * out[j][q*sp + s] = beta * W0[j][q*sp + s]
  *                  + alpha * sum_{e in col j of R} rv[e] * sum_{f in col q of P} cv[f] * W1[ri[e]][ci[f]*sp + s]

@@ -61,6 +61,9 @@ SIGNATURES = {
     'nif_kmeans_targets': (_i32, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     'nif_refit_pairs': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     'nif_refit_gather': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32, _vp, _vp]),
+    'nif_sinkhorn_workspace_bytes': (_sz, [_i32, _i32]),
+    'nif_sinkhorn_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _c.c_double, _i32, _c.c_double, _vp, _i64, _vp, _vp, _vp, _vp,
+                                _vp, _sz, _vp]),
     'nif_emd_workspace_bytes': (_sz, [_i32, _i32]),
     'nif_emd_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _c.c_double, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),

@@ -149,6 +149,10 @@ class OTFusion:
             self._prepare_acts_based_alignment(mode)
         if mode == 'acts':
             self._initialize_activations(fused_hat)  # target activations are captured once (otfusion.py:223-224)
+        if alignment_strategy.get('solver', 'emd') == 'sinkhorn':
+            return self._fuse_models_entropic(fused_hat, num_layers, input_dim, use_scores, handle_bias)
+        if alignment_strategy.get('solver', 'emd') != 'emd':
+            raise ValueError("alignment_strategy['solver'] must be 'emd' (the reference's exact plan) or 'sinkhorn'")
 
         # plans of the previous layer per model, as (row4col, None) -- row4col[j'] = model-k unit transported
         # to fused unit j' -- or (None, SparsePlan); (None, None) = the identity coupling diag(nu_prev) of the
@@ -269,6 +273,74 @@ class OTFusion:
             prev_is_conv = is_conv
             nu_prev = nu
 
+        if mode == 'acts':
+            for model in self.models:
+                model.remove_hooks()
+            self.target_model.remove_hooks()
+            fused_hat.remove_hooks()
+            with twin_copy():
+                fused_hat = fused_hat.copy_model()
+        return fused_hat
+
+    def _fuse_models_entropic(self, fused_hat, num_layers, input_dim, use_scores, handle_bias):
+        """The loop of otfusion.py:226-361 with DENSE plans from the library's Sinkhorn mode
+        (alignment_strategy['solver'] = 'sinkhorn', ['sinkhorn_reg'] = POT's `reg`, optional ['sinkhorn_iters'],
+        ['sinkhorn_tol']).  Not a reference path: the reference's plan is the exact ot.emd.  Dense plans make the
+        alignment plain matrix products (library GEMMs), as the reference writes them."""
+        st = self.alignment_strategy
+        mode, dev = st['mode'], self.device
+        reg = float(st['sinkhorn_reg'])
+        iters, tol = int(st.get('sinkhorn_iters', 1000)), float(st.get('sinkhorn_tol', 1e-9))
+        nu_prev = torch.ones(input_dim, device=dev) / input_dim
+        T_prev = [torch.diag(nu_prev) for _ in self.models]
+        prev_is_conv = False
+        self.plans, self.sinkhorn_log = [], []
+        for layer in range(num_layers):
+            print(f'Fusing layer {layer+1}/{num_layers}')
+            total_weight, is_conv = get_layer_weight(fused_hat, layer)
+            total_weight = total_weight.to(dev).clone()
+            n_f = total_weight.shape[0]
+            total_bias = None
+            if handle_bias:
+                total_bias = fused_hat.get_ordered_trainable_named_layers[layer].layer.bias.data.clone().detach().to(dev)
+            if use_scores:
+                nu = self.target_neuron_importance_scores[layer].to(dev)
+                nu = nu / nu.sum()
+            else:
+                nu = torch.ones(n_f, device=dev) / n_f
+            for k, model in enumerate(self.models):
+                wk, _ = get_layer_weight(model, layer)
+                wk = wk.to(dev)
+                n_k = get_layer_width(model, layer)
+                if use_scores:
+                    mu = self.neuron_importance_scores[k][layer].to(dev)
+                    mu = mu / mu.sum()
+                else:
+                    mu = torch.ones(n_k, device=dev) / n_k
+                Tp = T_prev[k] @ torch.diag(1.0 / nu_prev)  # (otfusion.py:283-303)
+                if is_conv:
+                    edges = torch.einsum('ois,ij->ojs', wk, Tp)
+                elif prev_is_conv:
+                    edges = torch.einsum('ois,ij->ojs', wk.view(n_k, Tp.shape[0], -1), Tp).flatten(1)
+                else:
+                    edges = wk @ Tp
+                C = self._get_ground_metric(model, fused_hat, layer, edges if mode == 'wts' else None)
+                res = ops.sinkhorn(C, mu, nu, reg, max_iter=iters, tol=tol)
+                self.sinkhorn_log.append(dict(layer=layer, model=k, state=res['state'], iterations=res['iterations'],
+                                              err=res['err']))
+                T = res['T']
+                self.plans.append((layer, k, T))
+                T_prev[k] = T
+                Tc = T.T @ torch.diag(1.0 / mu) if layer < num_layers - 1 else torch.eye(n_k, device=dev)
+                total_weight += (Tc @ edges.flatten(1)).view_as(total_weight)
+                if handle_bias:
+                    bk = model.get_ordered_trainable_named_layers[layer].layer.bias.detach().to(dev)
+                    total_bias += (Tc @ bk).view_as(total_bias)
+            scale = 1.0 / (len(self.models) + 1)
+            fused_hat.set_weight_at_layer(layer, total_weight * scale)
+            if handle_bias:
+                fused_hat.set_bias_at_layer(layer, total_bias * scale)
+            nu_prev, prev_is_conv = nu, is_conv
         if mode == 'acts':
             for model in self.models:
                 model.remove_hooks()

@@ -788,6 +788,34 @@ def emd_solve_many(problems, duals=False):
     return [_emd_result(p, w, duals) for p, w in zip(ps, works)]
 
 
+def sinkhorn(C, a, b, reg, max_iter=1000, tol=1e-9):
+    """Entropic transport plan diag(u) exp(-C / reg) diag(v) by Sinkhorn-Knopp iterations (POT's
+    ``ot.sinkhorn(a, b, C, reg)``; NOT what the reference calls -- it uses the exact ot.emd -- an additional approximate
+    mode).  Returns dict(T (n0 x n1 f32), u, v (f64), state (0 cap reached / 1 converged / 2 breakdown), iterations,
+    err)."""
+    _need_gpu(C, a, b)
+    C = _mat(C.float(), 'C')
+    n0, n1 = C.shape
+    dev = C.device
+    a = a.to(device=dev, dtype=torch.float64).contiguous()
+    b = b.to(device=dev, dtype=torch.float64).contiguous()
+    if a.numel() != n0 or b.numel() != n1:
+        raise ValueError(f'marginals {a.numel()}, {b.numel()} do not match the cost {n0} x {n1}')
+    with torch.cuda.device(dev):
+        T = torch.empty((n0, n1), dtype=torch.float32, device=dev)
+        u = torch.empty(n0, dtype=torch.float64, device=dev)
+        v = torch.empty(n1, dtype=torch.float64, device=dev)
+        info = torch.zeros(2, dtype=torch.int32, device=dev)
+        err = torch.zeros((), dtype=torch.float64, device=dev)
+        wsz = lib.nif_sinkhorn_workspace_bytes(n0, n1)
+        ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+        check(lib.nif_sinkhorn_f32(_ptr(C), _ld(C), n0, n1, _ptr(a), _ptr(b), float(reg), int(max_iter), float(tol), _ptr(T),
+                                   n1, _ptr(u), _ptr(v), _ptr(info), _ptr(err), _ptr(ws), wsz, _stream()),
+              'nif_sinkhorn_f32')
+        state, iters = info.tolist()
+    return dict(T=T, u=u, v=v, state=state, iterations=iters, err=float(err))
+
+
 def refit_sparse(W0, W1, rows=None, cols=None, alpha=1.0, beta=1.0, sp=1):
     """out = beta * W0 + alpha * R W1 P with sparse R (n_out x n_k, given as the CSC triplet of its transpose:
     column j lists the model-k rows feeding fused row j) and sparse P acting on the input units (column q lists

@@ -36,6 +36,35 @@ def emd(mu, nu, cost):
     return torch.from_numpy(res.x.reshape(n0, n1)).float()
 
 
+def sinkhorn_knopp(mu, nu, cost, reg, num_iter_max=1000, stop_thr=1e-9):
+    """Entropic plan by Sinkhorn-Knopp, restating the published algorithm of POT's ``ot.sinkhorn(a, b, M, reg)``
+    (method 'sinkhorn', POT 0.9.x bregman `sinkhorn_knopp`) in f64.  PARITY UNPINNED: POT is not installed and the
+    reference never calls it (it uses ot.emd); this is the checker of the library's additional Sinkhorn mode."""
+    a = np.asarray(mu, dtype=np.float64)
+    b = np.asarray(nu, dtype=np.float64)
+    M = np.asarray(cost, dtype=np.float64)
+    u = np.ones(a.shape[0]) / a.shape[0]
+    v = np.ones(b.shape[0]) / b.shape[0]
+    K = np.exp(-M / reg)
+    Kp = (1.0 / a).reshape(-1, 1) * K
+    iters = 0
+    for ii in range(num_iter_max):
+        uprev, vprev = u, v
+        KtU = K.T @ u
+        with np.errstate(divide='ignore', invalid='ignore'):
+            v = b / KtU
+            u = 1.0 / (Kp @ v)
+        if np.any(KtU == 0) or not np.all(np.isfinite(u)) or not np.all(np.isfinite(v)):
+            u, v = uprev, vprev
+            break
+        iters = ii + 1
+        if ii % 10 == 0:
+            tmp2 = np.einsum('i,ij,j->j', u, K, v)
+            if np.linalg.norm(tmp2 - b) < stop_thr:
+                break
+    return torch.from_numpy(u.reshape(-1, 1) * K * v.reshape(1, -1)).float(), iters
+
+
 def ground_metric_acts(act1, act2, normalize=False):
     """Euclidean distance between neuron activation vectors, otfusion.py:135-161."""
     if normalize:
@@ -49,10 +78,11 @@ def ground_metric_wts(aligned_weight, fused_weight):
 
 
 def otf_fuse(models, target_model, X=None, mode='acts', normalize=False, handle_bias=True, log=None, scores=None,
-             target_scores=None):
+             target_scores=None, solver=None):
     """OTFusion.fuse_models with handle_skip=False, otfusion.py:193-361.  scores[k][l] / target_scores[l]:
     neuron importances already rescaled as otfusion.py:110-112 asks (None = the uniform marginals of
-    :242,258); they are normalised to sum 1 here as :239-240,255-256 do."""
+    :242,258); they are normalised to sum 1 here as :239-240,255-256 do.  solver(mu, nu, C) -> T replaces the exact
+    plan (the library's additional Sinkhorn mode)."""
     for m in models:
         m.eval()
     target_model.eval()
@@ -99,7 +129,7 @@ def otf_fuse(models, target_model, X=None, mode='acts', normalize=False, handle_
                 C = ground_metric_acts(a1, a2, normalize)
             else:
                 C = ground_metric_wts(edges, fused.get_ordered_trainable_named_layers[l].weight)
-            T = emd(mu, nu, C.detach())
+            T = emd(mu, nu, C.detach()) if solver is None else solver(mu, nu, C.detach())
             T_prev[k] = T
             Tc = T.T @ torch.diag(1 / mu)
             if l == n_layers - 1:

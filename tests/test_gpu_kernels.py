@@ -361,6 +361,37 @@ def test_emd_solve_many_equals_one_by_one(ops):
         assert torch.equal(plan.val, one.val) and torch.equal(u, u1) and torch.equal(v, v1)
 
 
+@pytest.mark.parametrize('n0,n1,reg', [(17, 17, 0.1), (64, 48, 0.05), (384, 384, 0.05), (300, 771, 0.08), (1024, 1024, 0.02)])
+def test_sinkhorn_matches_the_f64_restatement(ops, n0, n1, reg):
+    """The additional Sinkhorn mode against oracle.otfusion.sinkhorn_knopp (POT's algorithm restated, parity unpinned):
+    same iteration count (the stopping rule is evaluated on the same iterations), plan and marginals."""
+    from oracle.otfusion import sinkhorn_knopp
+    g = torch.Generator().manual_seed(n0 * 7 + n1)
+    C = torch.rand(n0, n1, generator=g)
+    a = torch.rand(n0, generator=g).double() + 0.1
+    b = torch.rand(n1, generator=g).double() + 0.1
+    a, b = a / a.sum(), b / b.sum()
+    res = ops.sinkhorn(C.cuda(), a.cuda(), b.cuda(), reg)
+    T_ref, iters = sinkhorn_knopp(a.numpy(), b.numpy(), C.numpy(), reg)
+    assert res['state'] == 1 and res['iterations'] == iters
+    T = res['T'].cpu()
+    np.testing.assert_allclose(T.numpy(), T_ref.numpy(), rtol=2e-5, atol=1e-12)
+    np.testing.assert_allclose(T.double().sum(0).numpy(), b.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(T.double().sum(1).numpy(), a.numpy(), rtol=1e-4)
+
+
+def test_sinkhorn_iteration_cap_and_breakdown(ops):
+    g = torch.Generator().manual_seed(3)
+    C = torch.rand(40, 40, generator=g).cuda()
+    a = torch.full((40,), 1 / 40, dtype=torch.float64).cuda()
+    res = ops.sinkhorn(C, a, a, 0.01, max_iter=7)
+    assert res['state'] == 0 and res['iterations'] == 7
+    # a regularisation so small that exp(-C / reg) underflows to zero everywhere: POT stops with a warning and
+    # returns the initial scalings; so does the kernel (state 2, no iteration completed, finite plan)
+    res = ops.sinkhorn(C + 1.0, a, a, 1e-4)
+    assert res['state'] == 2 and res['iterations'] == 0 and bool(torch.isfinite(res['T']).all())
+
+
 def test_emd_degenerate_and_uniform_cases(ops):
     """Ties / degenerate vertices: the plan need not be unique, the optimal value is."""
     g = torch.Generator().manual_seed(5)
