@@ -163,9 +163,9 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ['NIF_BENCH_WATCHDOG']), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--workload', choices=['c2', 'c1', 'c3', 'c4'], default='c2',
+    ap.add_argument('--workload', choices=['c2', 'c1', 'c3', 'c4', 'sk'], default='c2',
                     help='c2 (default): the per-level throughput benchmark; c1 / c3 / c4: end-to-end fusion wall-clock of '
-                         'BASELINE.json configs 1 / 3 / 4 on one GPU (bench_e2e.py)')
+                         'BASELINE.json configs 1 / 3 / 4 on one GPU; sk: the additional Sinkhorn mode (bench_e2e.py)')
     ap.add_argument('--steps', type=int, default=None, help='timed steps (default 200 levels; 5 fusions for c1/c3/c4)')
     ap.add_argument('--warmup', type=int, default=None, help='untimed steps (default 10; 1 for c1/c3/c4)')
     ap.add_argument('--hard-steps', type=int, default=20, help='timed levels of the hard-assignment variant (N = 1)')

@@ -182,13 +182,39 @@ def run_c4(ops, device, steps, warmup, batch=5000, depth=7):
                   'share_of_wall_clock': xty_ms * 1e-3 / sum(times) if times else None})
 
 
-RUNNERS = {'c1': run_c1, 'c3': run_c3, 'c4': run_c4}
+def run_sk(ops, device, steps, warmup, n=8192, iters=200):
+    """The additional Sinkhorn mode (not a reference path): `iters` iterations on an n x n cost, uniform marginals."""
+    g = torch.Generator(device=device).manual_seed(0)
+    C = torch.rand(n, n, device=device, generator=g)
+    a = torch.full((n,), 1.0 / n, dtype=torch.float64, device=device)
+    state = {}
+
+    def solve():
+        state['r'] = ops.sinkhorn(C, a, a, 0.05, max_iter=iters, tol=0.0)
+
+    times = _timed(solve, steps, max(warmup, 1))
+    sec = float(np.mean(times))
+    achieved = 8.0 * n * n * iters / sec / 1e9
+    return dict(
+        seconds=sec,
+        workload=f'Sinkhorn mode (additional, approximate; the reference uses exact ot.emd): {iters} iterations on a '
+                 f'{n} x {n} cost, uniform marginals, reg 0.05; whole ops.sinkhorn() wall-clock incl. K build and plan',
+        extra={'seconds_each': [round(t, 5) for t in times], 'iterations': state['r']['iterations'],
+               'marginal_error': state['r']['err'], 'us_per_iteration': sec / iters * 1e6},
+        roofline={'kernel': 'nif::sk_colpass_kernel + sk_colfinish_kernel + sk_rowpass_kernel (one Sinkhorn iteration)',
+                  'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                  'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes': 8.0 * n * n * iters,
+                  'note': '8 n^2 bytes per iteration (K f32 streamed twice); wall-clock of the whole call, so the '
+                          'K build, the plan and the host round trips every 50 iterations are inside'})
+
+
+RUNNERS = {'c1': run_c1, 'c3': run_c3, 'c4': run_c4, 'sk': run_sk}
 
 
 def run(workload, ops, device, steps, warmup):
     r = RUNNERS[workload](ops, device, steps, warmup)
     return {
-        'metric': 'end-to-end fusion wall-clock', 'value': r['seconds'], 'unit': 's', 'n_gpus': 1, 'steps': steps,
+        'metric': 'sinkhorn solve wall-clock' if workload == 'sk' else 'end-to-end fusion wall-clock', 'value': r['seconds'], 'unit': 's', 'n_gpus': 1, 'steps': steps,
         'warmup': max(warmup, 1), 'ms_per_step': r['seconds'] * 1e3, 'higher_is_better': False, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f32 inputs; f64 normal equations / duals', 'data': 'synthetic',
         'config': dict(workload=r['workload'], **r['extra']), 'roofline': r['roofline'],

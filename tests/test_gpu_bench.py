@@ -40,3 +40,10 @@ def test_c1_workload_reports_the_tridiagonalisation(ops):
     assert r['roofline']['eigensolver_calls'] > 0 and r['roofline']['achieved'] > 0
     assert r['config']['hf2_seconds'] > 0
     json.dumps(r)
+
+
+def test_sinkhorn_workload_runs_at_reduced_size(ops):
+    import bench_e2e
+    r = bench_e2e.run_sk(ops, torch.device('cuda', 0), 1, 1, n=512, iters=30)
+    assert r['extra']['iterations'] == 30 and r['roofline']['achieved'] > 0
+    json.dumps(r)
