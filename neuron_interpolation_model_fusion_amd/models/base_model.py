@@ -137,11 +137,17 @@ class BaseModel(nn.Module, ABC):
     # -- activation capture (base_model.py:103-133) --------------------------------
     def register_hooks(self):
         names = {rep.layer: rep.name for rep in self.get_ordered_trainable_named_layers}
+        # The reference clones every captured tensor (base_model.py:110-118).  A clone only matters if something
+        # writes into the tensor after the hook has seen it, i.e. if the model holds an in-place module (ReLU(inplace=
+        # True), Dropout(inplace=True), ...): none of the reference's architectures does, so the captures alias the
+        # forward's own tensors (no copy pass, the same memory footprint as the clones had).
+        must_clone = any(getattr(m, 'inplace', False) for m in self.modules())
 
         def capture(module, inputs, output):
             name = names[module]
-            self.layer_inputs[name] = inputs[0].detach().clone()
-            self.layer_outputs[name] = output.detach().clone()
+            x, y = inputs[0].detach(), output.detach()
+            self.layer_inputs[name] = x.clone() if must_clone else x
+            self.layer_outputs[name] = y.clone() if must_clone else y
 
         for rep in self.get_ordered_trainable_named_layers:
             self.handles[rep.name] = rep.layer.register_forward_hook(capture)

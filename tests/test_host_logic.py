@@ -167,3 +167,30 @@ def test_alf_last_level_grouping_and_criterion_branches_match_reference_golden()
     hidden = alf._get_criterion(0, 32, torch.cat([torch.arange(32)] * 2),
                                 cfg(use_weighted_loss=True, cls_head_weights=head_w, use_kd_on_head=True), False)
     assert hidden.__name__ == 'weighted_loss'
+
+
+def test_hook_capture_aliases_unless_the_model_has_an_inplace_module():
+    """K1: captures are the forward's own tensors (no clone pass) unless an in-place module could overwrite them."""
+    import torch
+    from torch import nn
+    from neuron_interpolation_model_fusion_amd.models import MLPNet
+    torch.manual_seed(0)
+    m = MLPNet(12, 16, 4, use_bias=True, use_activations=True).eval()
+    x = torch.randn(5, 1, 3, 4)
+    m.register_hooks()
+    with torch.no_grad():
+        out = m(x)
+    inp, pre = m.get_inputs_and_preactivations(1)
+    assert pre.data_ptr() == out.data_ptr()  # the last layer's capture IS the output tensor
+    fc1 = m.get_ordered_trainable_named_layers[0].layer
+    ref = fc1(x.flatten(1))
+    assert torch.allclose(m.get_inputs_and_preactivations(0)[1], ref)
+    m.remove_hooks()
+    # an in-place activation after the layer: the capture must survive it
+    m.level1.append(nn.ReLU(inplace=True))
+    m.register_hooks()
+    with torch.no_grad():
+        m(x)
+    pre0 = m.get_inputs_and_preactivations(0)[1]
+    assert torch.allclose(pre0, ref) and bool((pre0 < 0).any())
+    m.remove_hooks()
