@@ -303,11 +303,12 @@ struct MmaF64 {
 
 // ---- main kernel -----------------------------------------------------------------------------------
 
-// waves per SIMD the register budget is sized for: 4 for the 128-wide f32 tile (64 accumulator
-// registers), 2 for the 192-wide f32 tile and for the f64 forms
+// waves per SIMD the register budget is sized for: 3 for the 128-wide f32 tile (64 accumulator registers; at 4 waves
+// = 128 registers it spilled 60-76 bytes per lane and was no faster: 105 vs 113 TF at n = 6144, 102 vs 106 at 1024),
+// 2 for the 192-wide f32 tile and for the f64 forms
 template <template <int, int> class MmaT, int FI>
 constexpr int xty_waves_per_simd() {
-  return (sizeof(typename MmaT<FI, FI>::acc_t) == 4 && FI == 2) ? 4 : 2;
+  return (sizeof(typename MmaT<FI, FI>::acc_t) == 4 && FI == 2) ? 3 : 2;
 }
 
 template <typename Tin, template <int, int> class MmaT, int FI, int FJ, bool RELU_A, bool RELU_B, bool TA, bool TB>
@@ -812,7 +813,7 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   // fill the chip (256 CUs x resident workgroups per CU) without leaving a second, nearly empty
   // round of workgroups; keep >= 4 K-tiles per row block
   const bool split_bf16 = (flags & NIF_XTY_SPLIT_BF16) != 0;
-  pl.slots = 256 * (split_bf16 ? (f == 3 ? 1 : 2) : (f == 3 ? 2 : (in_f64 || acc == NIF_F64 ? 2 : 4)));
+  pl.slots = 256 * (split_bf16 ? (f == 3 ? 1 : 2) : (f == 3 ? 2 : (in_f64 || acc == NIF_F64 ? 2 : 3)));
   pl.slots /= slot_div;
   static const int slots_override = env_int("NIF_XTY_SLOTS");  // tuning aid: workgroups the split-K aims for
   if (slots_override >= 1) pl.slots = slots_override;
