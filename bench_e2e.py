@@ -212,7 +212,12 @@ RUNNERS = {'c1': run_c1, 'c3': run_c3, 'c4': run_c4, 'sk': run_sk}
 
 
 def run(workload, ops, device, steps, warmup):
-    r = RUNNERS[workload](ops, device, steps, warmup)
+    from neuron_interpolation_model_fusion_amd.models.base_model import twin_copy
+    saved = twin_copy.replay_init_draws  # the runners switch the discarded initialisation off: put it back
+    try:
+        r = RUNNERS[workload](ops, device, steps, warmup)
+    finally:
+        twin_copy.replay_init_draws = saved
     return {
         'metric': 'sinkhorn solve wall-clock' if workload == 'sk' else 'end-to-end fusion wall-clock', 'value': r['seconds'], 'unit': 's', 'n_gpus': 1, 'steps': steps,
         'warmup': max(warmup, 1), 'ms_per_step': r['seconds'] * 1e3, 'higher_is_better': False, 'scaling': 'strong',
