@@ -246,6 +246,22 @@ int nif_kmeans_lloyd_step_gf32(const float* G, int64_t ldg, const double* gdiag,
 int nif_kmeans_repair_kf(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N,
                          int k, int32_t* changed, void* ws, size_t ws_bytes, void* stream);
 
+/* KF's tries of one layer advance together (hf_kf.py:420-475 runs them one after the other; they share G, nn, s and
+ * differ in their assignment): tries_idx (HOST array, n_tries <= 16 entries, each < 16) names the tries this call
+ * advances; assign / assign_out / nearest are rows of [tries][N] tensors, cost / kprime / changed entries of [tries]
+ * vectors, ws holds one nif_kmeans_workspace_bytes(N, k) block per try, back to back.  Same results as the
+ * single-problem calls, one launch per kernel for the whole batch. */
+int nif_kmeans_lloyd_step_batch(const double* G, int64_t ldg, const double* nn, const float* s, const int32_t* assign,
+                                int N, int k, const int32_t* tries_idx, int n_tries, int32_t* assign_out,
+                                double* nearest, double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream);
+int nif_kmeans_lloyd_step_batch_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, const float* s,
+                                     const int32_t* assign, int N, int k, const int32_t* tries_idx, int n_tries,
+                                     int32_t* assign_out, double* nearest, double* cost, int32_t* kprime, void* ws,
+                                     size_t ws_bytes, void* stream);
+int nif_kmeans_repair_kf_batch(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N, int k,
+                               const int32_t* tries_idx, int n_tries, int32_t* changed, void* ws, size_t ws_bytes,
+                               void* stream);
+
 /* Fused neurons from a clustering, hf_kf.py:283-312,494-504: out[cc][r] = sum_{i in c} s_i W[r][i] / S_c
  * for the non-empty clusters in label order (rows >= *kprime stay zero). W: d x N f64 (LS solutions
  * as columns), out: k x d f32. */

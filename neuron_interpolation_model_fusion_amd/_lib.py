@@ -56,6 +56,10 @@ SIGNATURES = {
     'nif_kmeans_farthest_init_batch_gf32': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     'nif_kmeans_assign_to_neurons_gf32': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'nif_kmeans_lloyd_step_gf32': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nif_kmeans_lloyd_step_batch': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nif_kmeans_lloyd_step_batch_gf32': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz,
+                                                _vp]),
+    'nif_kmeans_repair_kf_batch': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     'nif_kmeans_repair_kf': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     'nif_kmeans_centroid_weights': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'nif_kmeans_targets': (_i32, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),

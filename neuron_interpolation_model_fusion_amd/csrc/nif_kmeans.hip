@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/nif.h"
 #include "nif_common.h"
@@ -62,6 +63,24 @@ constexpr int FI_MAX_TRIES = 16;
 struct FiFirsts {
   int first[FI_MAX_TRIES];
 };
+
+// The Lloyd-step kernels take a batch of k-means problems over the SAME G, nn, s (KF's tries): blockIdx.y walks the
+// batch, idx[] names the try each entry works on (the tries still alive), every per-try array is a row of a
+// [tries][...] tensor and every workspace pointer belongs to try 0's workspace, ws_stride bytes before the next one's.
+struct KmBatch {
+  int idx[FI_MAX_TRIES];
+  long long ws_stride;
+};
+template <typename T>
+__device__ __forceinline__ T* kb_ws(T* p, const KmBatch& kb) {
+  typedef typename std::remove_const<T>::type U;
+  return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(const_cast<U*>(p)) +
+                              (size_t)kb.idx[blockIdx.y] * (size_t)kb.ws_stride);
+}
+template <typename T>
+__device__ __forceinline__ T* kb_row(T* p, const KmBatch& kb, size_t n) {
+  return p + (size_t)kb.idx[blockIdx.y] * n;
+}
 
 // ---- farthest-point initialisation (hf_kf.py:424-441), one workgroup ----------------------------
 // picks[0] = first; picks[c] = argmax_j min_{c' < c} dist(centroid c', neuron j), where centroid c'
@@ -326,7 +345,9 @@ __global__ void kmeans_assign_to_neurons_kernel(const GT* __restrict__ G, int64_
 // ---- Lloyd step -----------------------------------------------------------------------------------
 
 // counts[label]++ (counts zeroed by the caller)
-__global__ void kmeans_count_kernel(const int* __restrict__ assign, int N, int* __restrict__ counts) {
+__global__ void kmeans_count_kernel(const int* __restrict__ assign, int N, int* __restrict__ counts, KmBatch kb) {
+  assign = kb_row(assign, kb, N);
+  counts = kb_ws(counts, kb);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) atomicAdd(&counts[assign[i]], 1);
 }
@@ -335,7 +356,11 @@ __global__ void kmeans_count_kernel(const int* __restrict__ assign, int N, int* 
 // *kprime = number of non-empty clusters.  One workgroup: lane t owns a run of consecutive clusters.
 __global__ __launch_bounds__(1024) void kmeans_scan_kernel(const int* __restrict__ counts, int k,
                                                            int* __restrict__ seg, int* __restrict__ compact,
-                                                           int* __restrict__ kprime) {
+                                                           int* __restrict__ kprime, KmBatch kb) {
+  counts = kb_ws(counts, kb);
+  seg = kb_ws(seg, kb);
+  compact = kb_ws(compact, kb);
+  kprime = kb_row(kprime, kb, 1);
   __shared__ int wsum[16], wlive[16];
   const int per = (k + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(lo + per, k);
@@ -382,7 +407,10 @@ __global__ __launch_bounds__(1024) void kmeans_scan_kernel(const int* __restrict
 // order[seg[c] ...] = members of cluster c in ascending index order; one wavefront per cluster sweeps the
 // labels (L2-resident) and compacts its matches with a ballot.
 __global__ __launch_bounds__(256) void kmeans_members_kernel(const int* __restrict__ assign, const int* __restrict__ seg,
-                                                             int N, int k, int* __restrict__ order) {
+                                                             int N, int k, int* __restrict__ order, KmBatch kb) {
+  assign = kb_row(assign, kb, N);
+  seg = kb_ws(seg, kb);
+  order = kb_ws(order, kb);
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= k) return;
   const int lane = threadIdx.x & 63;
@@ -407,7 +435,11 @@ __global__ __launch_bounds__(256) void kmeans_members_kernel(const int* __restri
 
 // S[cc] = sum of the member weights of cluster c, in member order (one lane per cluster)
 __global__ void kmeans_S_kernel(const float* __restrict__ s, const int* __restrict__ order, const int* __restrict__ seg,
-                                const int* __restrict__ compact, int k, double* __restrict__ S) {
+                                const int* __restrict__ compact, int k, double* __restrict__ S, KmBatch kb) {
+  order = kb_ws(order, kb);
+  seg = kb_ws(seg, kb);
+  compact = kb_ws(compact, kb);
+  S = kb_ws(S, kb);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= k) return;
   const int cc = compact[c];
@@ -419,7 +451,9 @@ __global__ void kmeans_S_kernel(const float* __restrict__ s, const int* __restri
 
 // cost = sum of the per-block partials: lane l adds partial[l], partial[l + 64], ... in order, then a fixed tree
 __global__ __launch_bounds__(64) void kmeans_cost_kernel(const double* __restrict__ partial, int nblocks,
-                                                         double* __restrict__ cost) {
+                                                         double* __restrict__ cost, KmBatch kb) {
+  partial = kb_ws(partial, kb);
+  cost = kb_row(cost, kb, 1);
   double t = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 64) t += partial[b];
   t = wave_sum_f64(t);
@@ -437,7 +471,13 @@ __global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const
                                     const float* __restrict__ s,
                                     const int* __restrict__ order, const int* __restrict__ assign,
                                     const int* __restrict__ seg, const int* __restrict__ compact,
-                                    const double* __restrict__ S, int N, double* __restrict__ hself) {
+                                    const double* __restrict__ S, int N, double* __restrict__ hself, KmBatch kb) {
+  order = kb_ws(order, kb);
+  seg = kb_ws(seg, kb);
+  compact = kb_ws(compact, kb);
+  S = kb_ws(S, kb);
+  hself = kb_ws(hself, kb);
+  assign = kb_row(assign, kb, N);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // sorted position: a wave's lanes share clusters
   if (t >= N) return;
   const int i = order[t];
@@ -454,7 +494,13 @@ __global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const
 __global__ void kmeans_cn_self_kernel(const double* __restrict__ hself, const float* __restrict__ s,
                                       const int* __restrict__ order, const int* __restrict__ seg,
                                       const int* __restrict__ compact, const double* __restrict__ S, int k,
-                                      double* __restrict__ cn) {
+                                      double* __restrict__ cn, KmBatch kb) {
+  hself = kb_ws(hself, kb);
+  order = kb_ws(order, kb);
+  seg = kb_ws(seg, kb);
+  compact = kb_ws(compact, kb);
+  S = kb_ws(S, kb);
+  cn = kb_ws(cn, kb);
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= k) return;
   const int cc = compact[c];
@@ -471,7 +517,9 @@ __global__ void kmeans_cn_self_kernel(const double* __restrict__ hself, const fl
 
 // ssorted[t] = s[order[t]]: the member weights in the order the pass below walks them
 __global__ void kmeans_ssorted_kernel(const float* __restrict__ s, const int* __restrict__ order, int N,
-                                      float* __restrict__ ssorted) {
+                                      float* __restrict__ ssorted, KmBatch kb) {
+  order = kb_ws(order, kb);
+  ssorted = kb_ws(ssorted, kb);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < N) ssorted[t] = s[order[t]];
 }
@@ -486,7 +534,16 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
     const int* __restrict__ order, const int* __restrict__ seg, const int* __restrict__ compact,
     const double* __restrict__ S,
     const double* __restrict__ cn, const double* __restrict__ nn, const float* __restrict__ s, int N, int k,
-    int* __restrict__ assign_out, double* __restrict__ nearest, double* __restrict__ partial) {
+    int* __restrict__ assign_out, double* __restrict__ nearest, double* __restrict__ partial, KmBatch kb) {
+  ssorted = kb_ws(ssorted, kb);
+  order = kb_ws(order, kb);
+  seg = kb_ws(seg, kb);
+  compact = kb_ws(compact, kb);
+  S = kb_ws(S, kb);
+  cn = kb_ws(cn, kb);
+  partial = kb_ws(partial, kb);
+  assign_out = kb_row(assign_out, kb, N);
+  nearest = kb_row(nearest, kb, N);
   __shared__ double cand_v[16][64];
   __shared__ int cand_c[16][64];
   const int tx = threadIdx.x & 63;
@@ -561,7 +618,12 @@ __global__ __launch_bounds__(1024) void kmeans_repair_kf_kernel(int* __restrict_
                                                                 const float* __restrict__ s,
                                                                 const int* __restrict__ prev, int N, int k,
                                                                 int* __restrict__ counts,
-                                                                int* __restrict__ changed) {
+                                                                int* __restrict__ changed, KmBatch kb) {
+  assign = kb_row(assign, kb, N);
+  nearest = kb_row(nearest, kb, N);
+  prev = kb_row(prev, kb, N);
+  counts = kb_ws(counts, kb);
+  changed = kb_row(changed, kb, 1);
   __shared__ double sv[16];
   __shared__ int sj[16];
   __shared__ int flag;
@@ -958,15 +1020,26 @@ static KmWs km_ws(int N, int k) {
 }
 
 // builds order / seg / compact / kprime for `assign` inside the workspace
-static void km_group(const int* assign, int N, int k, const KmWs& w, unsigned char* b, int* kprime, hipStream_t st) {
+static KmBatch km_single() {
+  KmBatch kb;
+  for (int t = 0; t < FI_MAX_TRIES; ++t) kb.idx[t] = 0;
+  kb.ws_stride = 0;
+  return kb;
+}
+
+// builds order / seg / compact / kprime for `assign` inside the workspace (of every try of the batch)
+static void km_group(const int* assign, int N, int k, const KmWs& w, unsigned char* b, int* kprime, hipStream_t st,
+                     const KmBatch& kb = km_single(), int L = 1) {
   int* counts = reinterpret_cast<int*>(b + w.off_counts);
   int* seg = reinterpret_cast<int*>(b + w.off_seg);
   int* compact = reinterpret_cast<int*>(b + w.off_compact);
   int* order = reinterpret_cast<int*>(b + w.off_order);
-  (void)hipMemsetAsync(counts, 0, (size_t)k * 4, st);
-  hipLaunchKernelGGL(kmeans_count_kernel, dim3(w.nblk), dim3(256), 0, st, assign, N, counts);
-  hipLaunchKernelGGL(kmeans_scan_kernel, dim3(1), dim3(1024), 0, st, counts, k, seg, compact, kprime);
-  hipLaunchKernelGGL(kmeans_members_kernel, dim3((k + 3) / 4), dim3(256), 0, st, assign, seg, N, k, order);
+  for (int e = 0; e < L; ++e)
+    (void)hipMemsetAsync(reinterpret_cast<unsigned char*>(counts) + (size_t)kb.idx[e] * (size_t)kb.ws_stride, 0,
+                         (size_t)k * 4, st);
+  hipLaunchKernelGGL(kmeans_count_kernel, dim3(w.nblk, L), dim3(256), 0, st, assign, N, counts, kb);
+  hipLaunchKernelGGL(kmeans_scan_kernel, dim3(1, L), dim3(1024), 0, st, counts, k, seg, compact, kprime, kb);
+  hipLaunchKernelGGL(kmeans_members_kernel, dim3((k + 3) / 4, L), dim3(256), 0, st, assign, seg, N, k, order, kb);
 }
 
 }  // namespace nif
@@ -1056,15 +1129,33 @@ static int km_assign_to_neurons(const GT* G, int64_t ldg, const double* gd, cons
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 
+// tries_idx (host, L entries, each in [0, FI_MAX_TRIES)): the tries this call advances; nullptr = the single problem
+static int km_batch(const int32_t* tries_idx, int L, size_t stride, size_t ws_bytes, KmBatch* kb) {
+  *kb = km_single();
+  if (!tries_idx) return L == 1 ? NIF_OK : NIF_ERR_INVALID_ARG;
+  if (L < 1 || L > FI_MAX_TRIES) return NIF_ERR_INVALID_ARG;
+  int top = 0;
+  for (int e = 0; e < L; ++e) {
+    if (tries_idx[e] < 0 || tries_idx[e] >= FI_MAX_TRIES) return NIF_ERR_INVALID_ARG;
+    kb->idx[e] = tries_idx[e];
+    if (tries_idx[e] > top) top = tries_idx[e];
+  }
+  kb->ws_stride = (long long)stride;
+  return ws_bytes >= (size_t)(top + 1) * stride ? NIF_OK : NIF_ERR_WORKSPACE;
+}
+
 template <typename GT>
-static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const double* nn, const float* s, const int32_t* assign, int N, int k,
-                         int32_t* assign_out, double* nearest, double* cost, int32_t* kprime, void* ws, size_t ws_bytes,
-                         void* stream) {
+static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const double* nn, const float* s,
+                         const int32_t* assign, int N, int k, const int32_t* tries_idx, int L, int32_t* assign_out,
+                         double* nearest, double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
   if (!G || !nn || !s || !assign || !assign_out || !nearest || !cost || !kprime || N <= 0 || k <= 0 || ldg < N ||
       (sizeof(GT) == 4 && !gd))
     return NIF_ERR_INVALID_ARG;
   const KmWs w = km_ws(N, k);
   if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
+  KmBatch kb;
+  const int brc = km_batch(tries_idx, L, w.total, ws_bytes, &kb);
+  if (brc != NIF_OK) return brc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   clear_err();
   unsigned char* b = reinterpret_cast<unsigned char*>(ws);
@@ -1077,17 +1168,35 @@ static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const doubl
   double* hself = reinterpret_cast<double*>(b + w.off_hself);
   float* ssorted = reinterpret_cast<float*>(b + w.off_wsorted);
   const int nb64 = (N + 63) / 64;
-  km_group(assign, N, k, w, b, kprime, st);
-  hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256), dim3(256), 0, st, s, order, seg, compact, k, S);
-  hipLaunchKernelGGL(kmeans_ssorted_kernel, dim3(w.nblk), dim3(256), 0, st, s, order, N, ssorted);
-  hipLaunchKernelGGL(kmeans_hself_kernel<GT>, dim3(w.nblk), dim3(256), 0, st, G, ldg, gd, s, order, assign, seg, compact, S,
-                     N, hself);
-  hipLaunchKernelGGL(kmeans_cn_self_kernel, dim3((k + 3) / 4), dim3(256), 0, st, hself, s, order, seg, compact, S, k, cn);
+  km_group(assign, N, k, w, b, kprime, st, kb, L);
+  hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256, L), dim3(256), 0, st, s, order, seg, compact, k, S, kb);
+  hipLaunchKernelGGL(kmeans_ssorted_kernel, dim3(w.nblk, L), dim3(256), 0, st, s, order, N, ssorted, kb);
+  hipLaunchKernelGGL(kmeans_hself_kernel<GT>, dim3(w.nblk, L), dim3(256), 0, st, G, ldg, gd, s, order, assign, seg, compact,
+                     S, N, hself, kb);
+  hipLaunchKernelGGL(kmeans_cn_self_kernel, dim3((k + 3) / 4, L), dim3(256), 0, st, hself, s, order, seg, compact, S, k, cn,
+                     kb);
   prof_begin(NIF_PROF_KMEANS, st);
-  hipLaunchKernelGGL(kmeans_nearest_fused_kernel<GT>, dim3(nb64), dim3(1024), 0, st, G, ldg, gd, ssorted, order, seg,
-                     compact, S, cn, nn, s, N, k, assign_out, nearest, partial);
+  hipLaunchKernelGGL(kmeans_nearest_fused_kernel<GT>, dim3(nb64, L), dim3(1024), 0, st, G, ldg, gd, ssorted, order, seg,
+                     compact, S, cn, nn, s, N, k, assign_out, nearest, partial, kb);
   prof_end(NIF_PROF_KMEANS, st);
-  hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1), dim3(64), 0, st, partial, nb64, cost);
+  hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1, L), dim3(64), 0, st, partial, nb64, cost, kb);
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+}
+
+static int km_repair_kf(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N, int k,
+                        const int32_t* tries_idx, int L, int32_t* changed, void* ws, size_t ws_bytes, void* stream) {
+  if (!assign || !nearest || !s || !prev || !changed || N <= 0 || k <= 0) return NIF_ERR_INVALID_ARG;
+  const KmWs w = km_ws(N, k);
+  if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
+  KmBatch kb;
+  const int brc = km_batch(tries_idx, L, w.total, ws_bytes, &kb);
+  if (brc != NIF_OK) return brc;
+  clear_err();
+  int* counts = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ws) + w.off_counts);
+  int threads = (N + 63) / 64 * 64;
+  if (threads > 1024) threads = 1024;
+  hipLaunchKernelGGL(kmeans_repair_kf_kernel, dim3(1, L), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream), assign,
+                     nearest, s, prev, N, k, counts, changed, kb);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 
@@ -1132,30 +1241,51 @@ extern "C" int nif_kmeans_lloyd_step(const double* G, int64_t ldg, const double*
                                      const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
                                      double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
   nif::Range nif_range_("nif_kmeans_lloyd_step");
-  return nif::km_lloyd_step<double>(G, ldg, nullptr, nn, s, assign, N, k, assign_out, nearest, cost, kprime, ws, ws_bytes, stream);
+  return nif::km_lloyd_step<double>(G, ldg, nullptr, nn, s, assign, N, k, nullptr, 1, assign_out, nearest, cost, kprime, ws,
+                                    ws_bytes, stream);
 }
 extern "C" int nif_kmeans_lloyd_step_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
                                           const float* s,
                                           const int32_t* assign, int N, int k, int32_t* assign_out, double* nearest,
                                           double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
   nif::Range nif_range_("nif_kmeans_lloyd_step_gf32");
-  return nif::km_lloyd_step<float>(G, ldg, gdiag, nn, s, assign, N, k, assign_out, nearest, cost, kprime, ws, ws_bytes, stream);
+  return nif::km_lloyd_step<float>(G, ldg, gdiag, nn, s, assign, N, k, nullptr, 1, assign_out, nearest, cost, kprime, ws,
+                                   ws_bytes, stream);
 }
 
 extern "C" int nif_kmeans_repair_kf(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N,
                                     int k, int32_t* changed, void* ws, size_t ws_bytes, void* stream) {
   nif::Range nif_range_("nif_kmeans_repair_kf");
-  using namespace nif;
-  if (!assign || !nearest || !s || !prev || !changed || N <= 0 || k <= 0) return NIF_ERR_INVALID_ARG;
-  const KmWs w = km_ws(N, k);
-  if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
-  clear_err();
-  int* counts = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ws) + w.off_counts);
-  int threads = (N + 63) / 64 * 64;
-  if (threads > 1024) threads = 1024;
-  hipLaunchKernelGGL(kmeans_repair_kf_kernel, dim3(1), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream), assign,
-                     nearest, s, prev, N, k, counts, changed);
-  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+  return nif::km_repair_kf(assign, nearest, s, prev, N, k, nullptr, 1, changed, ws, ws_bytes, stream);
+}
+
+// KF's tries advance together (hf_kf.py:420-475 runs them one after the other; they share G, nn and s): one launch
+// per kernel for all the tries named in tries_idx.
+extern "C" int nif_kmeans_lloyd_step_batch(const double* G, int64_t ldg, const double* nn, const float* s,
+                                           const int32_t* assign, int N, int k, const int32_t* tries_idx, int n_tries,
+                                           int32_t* assign_out, double* nearest, double* cost, int32_t* kprime,
+                                           void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_kmeans_lloyd_step_batch");
+  if (!tries_idx) return NIF_ERR_INVALID_ARG;
+  return nif::km_lloyd_step<double>(G, ldg, nullptr, nn, s, assign, N, k, tries_idx, n_tries, assign_out, nearest, cost,
+                                    kprime, ws, ws_bytes, stream);
+}
+extern "C" int nif_kmeans_lloyd_step_batch_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
+                                                const float* s, const int32_t* assign, int N, int k,
+                                                const int32_t* tries_idx, int n_tries, int32_t* assign_out,
+                                                double* nearest, double* cost, int32_t* kprime, void* ws,
+                                                size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_kmeans_lloyd_step_batch_gf32");
+  if (!tries_idx) return NIF_ERR_INVALID_ARG;
+  return nif::km_lloyd_step<float>(G, ldg, gdiag, nn, s, assign, N, k, tries_idx, n_tries, assign_out, nearest, cost,
+                                   kprime, ws, ws_bytes, stream);
+}
+extern "C" int nif_kmeans_repair_kf_batch(int32_t* assign, double* nearest, const float* s, const int32_t* prev, int N,
+                                          int k, const int32_t* tries_idx, int n_tries, int32_t* changed, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_kmeans_repair_kf_batch");
+  if (!tries_idx) return NIF_ERR_INVALID_ARG;
+  return nif::km_repair_kf(assign, nearest, s, prev, N, k, tries_idx, n_tries, changed, ws, ws_bytes, stream);
 }
 
 extern "C" int nif_kmeans_centroid_weights(const double* W, int64_t ldw, const float* s, const int32_t* assign, int N,
@@ -1205,7 +1335,7 @@ extern "C" int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const 
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kmeans_targets_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
-    hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w, order, seg, compact, k, S);
+    hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w, order, seg, compact, k, S, km_single());
     int64_t blocks = (m + R - 1) / R;
     if (blocks > 4096) blocks = 4096;
     const bool vec = (N % 4 == 0) && (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);

@@ -161,56 +161,58 @@ class LSFusion:
         else:
             GP, _, _ = ops.xty(R, W, acc='f64', norms=False)  # (XW)^T (XW) = R^T W
             GP, gdiag = ops.kmeans_gram_storage(GP)
-            km = ops.KMeans(GP, na, s, output_size, gdiag=gdiag)
+            T = num_k_means_tries
             best_assignment, best_total_cost = identity, np.inf
             start = time.time()
-            # The tries are independent, so they advance in lock step: every round launches one Lloyd step and one
-            # repair per live try and reads all their costs / change flags back with ONE synchronisation, where the
-            # reference's loop (and a try-by-try port) synchronises twice per step.  Each try keeps the exact
-            # control flow of hf_kf.py:448-475; the first-centroid draws come from np.random in try order.
+            # The tries are independent and share every matrix, so they advance in lock step as ONE batch: a round is
+            # one launch per kernel for all the tries still alive (nif_kmeans_lloyd_step_batch / repair_kf_batch) and
+            # ONE read-back of their costs / change flags, where the reference's loop (and a try-by-try port) launches
+            # and synchronises per try and step.  Each try keeps the exact control flow of hf_kf.py:448-475; the
+            # first-centroid draws come from np.random in try order.
             t0 = time.time()
-            # the farthest-point passes of all tries (same matrices, another first neuron each) are ONE launch: a try is
-            # one workgroup (or one row of workgroups), so they run side by side
-            firsts = [int(np.random.randint(low=0, high=output_size)) for _ in range(num_k_means_tries)]  # (:424)
-            tries = []
-            for lo in range(0, num_k_means_tries, 16):
-                _, assignments = km.farthest_init_many(firsts[lo:lo + 16])
-                for t in range(assignments.shape[0]):
-                    solver = km if lo + t == 0 else ops.KMeans(GP, na, s, output_size, gdiag=gdiag)  # own workspace per try
-                    tries.append(dict(km=solver, assignment=assignments[t], costs=[], live=True))
-            it_init = num_k_means_tries * (output_size - 1)
-            torch.cuda.synchronize(dev)
-            t_init = time.time() - t0
-            t0 = time.time()
-            it_conv = 0
-            while any(tr['live'] for tr in tries):
-                live = [tr for tr in tries if tr['live']]
-                flags = []
-                for tr in live:
-                    it_conv += 1
-                    prev = tr['assignment']
-                    assignment, nearest, cost, _ = tr['km'].lloyd_step(prev)
-                    tr['unrepaired'] = assignment.clone()  # kept if this step turns out to be the early stop
-                    changed = tr['km'].repair_kf(assignment, nearest, prev)
-                    tr['assignment'] = assignment
-                    flags.append(torch.stack([cost, changed.double()]))
-                for tr, (current_cost, changed) in zip(live, torch.stack(flags).tolist()):
-                    log = tr['costs']
-                    if len(log) >= k_means_early_stop_steps_check and current_cost >= \
-                            log[-k_means_early_stop_steps_check] * (1.0 - k_means_early_stop_minimum_improvement):
-                        print("K-means Early Stopping at ", len(log), " iterations since ", current_cost, " >= ",
-                              log[-k_means_early_stop_steps_check], "*",
-                              (1.0 - k_means_early_stop_minimum_improvement))
-                        tr['assignment'] = tr['unrepaired']  # before the repair (:460-462)
-                        tr['live'] = False
-                        continue
-                    log.append(current_cost)
-                    tr['live'] = bool(changed)
-            totals = torch.stack([tr['km'].lloyd_step(tr['assignment'])[2] for tr in tries]).tolist()
-            for tr, total_cost in zip(tries, totals):
-                if total_cost < best_total_cost:
-                    best_assignment, best_total_cost = tr['assignment'], total_cost
-            t_conv = time.time() - t0
+            firsts = [int(np.random.randint(low=0, high=output_size)) for _ in range(T)]  # (:424)
+            finals = [None] * T
+            logs = [[] for _ in range(T)]
+            it_init = T * (output_size - 1)
+            t_init, t_conv, it_conv = 0.0, 0.0, 0
+            for lo in range(0, T, 16):  # 16 tries per batch
+                ids = list(range(lo, min(T, lo + 16)))
+                km = ops.KMeans(GP, na, s, output_size, gdiag=gdiag, tries=len(ids))
+                _, A = km.farthest_init_many([firsts[t] for t in ids])
+                torch.cuda.synchronize(dev)
+                t_init += time.time() - t0
+                t0 = time.time()
+                live = list(range(len(ids)))
+                while live:
+                    it_conv += len(live)
+                    out, nearest, cost, _ = km.lloyd_step_many(A, live)
+                    unrepaired = out.clone()  # kept for a try whose step turns out to be its early stop
+                    changed = km.repair_kf_many(out, nearest, A, live)
+                    flags = torch.stack([cost, changed.double()], dim=1).tolist()
+                    still = []
+                    for e in live:
+                        current_cost, chg = flags[e]
+                        log = logs[ids[e]]
+                        if len(log) >= k_means_early_stop_steps_check and current_cost >= \
+                                log[-k_means_early_stop_steps_check] * (1.0 - k_means_early_stop_minimum_improvement):
+                            print("K-means Early Stopping at ", len(log), " iterations since ", current_cost, " >= ",
+                                  log[-k_means_early_stop_steps_check], "*",
+                                  (1.0 - k_means_early_stop_minimum_improvement))
+                            finals[ids[e]] = unrepaired[e].clone()  # before the repair (:460-462)
+                            continue
+                        log.append(current_cost)
+                        if chg:
+                            still.append(e)
+                        else:
+                            finals[ids[e]] = out[e].clone()
+                    A, live = out, still  # (rows of tries that have ended are never read again)
+                F = torch.stack([finals[t] for t in ids])
+                totals = km.lloyd_step_many(F)[2].tolist()
+                for t, total_cost in zip(ids, totals):
+                    if total_cost < best_total_cost:
+                        best_assignment, best_total_cost = finals[t], total_cost
+                t_conv += time.time() - t0
+                t0 = time.time()
             print(f'K-means time: {(time.time() - start):.2f}, Centroid Initialization Time: {t_init:.2f}, '
                   f'Centroid Initialization Iterations: {it_init}, Centroid Convergence Time: {t_conv:.2f}, '
                   f'Centroid Convergence Iterations: {it_conv}')

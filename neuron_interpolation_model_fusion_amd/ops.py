@@ -510,8 +510,11 @@ class KMeans:
     """Device state of one Gram-form k-means problem (see nif_kmeans_* in include/nif.h).  G: N x N f64, or f32 with
     its unrounded diagonal in `gdiag` (taken from G itself when not given)."""
 
-    def __init__(self, G, nn, s, k, gdiag=None):
+    def __init__(self, G, nn, s, k, gdiag=None, tries=1):
         _need_gpu(G, nn)
+        self.tries = int(tries)  # problems that share G, nn, s and advance together (the *_many methods)
+        if not 1 <= self.tries <= 16:
+            raise ValueError('KMeans: 1 <= tries <= 16')
         self.G = None if G is None else G.contiguous()  # None: only centroid_weights() / targets() may be used
         if self.G is not None and self.G.dtype not in (torch.float32, torch.float64):
             raise TypeError(f'KMeans: G must be float32 or float64, got {self.G.dtype}')
@@ -529,7 +532,7 @@ class KMeans:
             self._g = (_ptr(self.gdiag),)
         with torch.cuda.device(self.dev):
             self.nbytes = lib.nif_kmeans_workspace_bytes(self.N, self.k)
-            self.ws = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=self.dev)
+            self.ws = torch.empty(max(self.nbytes * self.tries, 1), dtype=torch.uint8, device=self.dev)
             self.mind = torch.empty(self.N, dtype=torch.float64, device=self.dev)
 
     def _i32(self, n):
@@ -578,6 +581,39 @@ class KMeans:
                      _ptr(out), _ptr(nearest), _ptr(cost), _ptr(kprime), _ptr(self.ws), self.nbytes, _stream()),
                   'nif_kmeans_lloyd_step' + self._sfx)
         return out, nearest, cost, kprime
+
+    def _live(self, live):
+        live = [int(t) for t in (range(self.tries) if live is None else live)]
+        if not live or min(live) < 0 or max(live) >= self.tries:
+            raise ValueError(f'tries {live} outside 0..{self.tries - 1}')
+        return (ctypes.c_int32 * len(live))(*live), len(live)
+
+    def lloyd_step_many(self, assign, live=None):
+        """lloyd_step for the tries in `live` (default: all) of assign [tries, N]: one launch per kernel for the batch.
+        Returns (assign_out [tries, N], nearest [tries, N], cost [tries], kprime [tries]); rows of other tries are
+        left unwritten."""
+        arr, L = self._live(live)
+        assign = assign.contiguous()
+        with torch.cuda.device(self.dev):
+            out = torch.empty((self.tries, self.N), dtype=torch.int32, device=self.dev)
+            nearest = torch.empty((self.tries, self.N), dtype=torch.float64, device=self.dev)
+            cost = torch.zeros(self.tries, dtype=torch.float64, device=self.dev)
+            kprime = torch.zeros(self.tries, dtype=torch.int32, device=self.dev)
+            fn = getattr(lib, 'nif_kmeans_lloyd_step_batch' + self._sfx)
+            check(fn(_ptr(self.G), self.G.stride(0), *self._g, _ptr(self.nn), _ptr(self.s), _ptr(assign), self.N, self.k,
+                     arr, L, _ptr(out), _ptr(nearest), _ptr(cost), _ptr(kprime), _ptr(self.ws), self.nbytes * self.tries,
+                     _stream()), 'nif_kmeans_lloyd_step_batch' + self._sfx)
+        return out, nearest, cost, kprime
+
+    def repair_kf_many(self, assign, nearest, prev, live=None):
+        """In-place KF repair of the rows `live` of assign / nearest [tries, N]; returns changed [tries] (int32)."""
+        arr, L = self._live(live)
+        with torch.cuda.device(self.dev):
+            changed = torch.zeros(self.tries, dtype=torch.int32, device=self.dev)
+            check(lib.nif_kmeans_repair_kf_batch(_ptr(assign), _ptr(nearest), _ptr(self.s), _ptr(prev), self.N, self.k,
+                                                 arr, L, _ptr(changed), _ptr(self.ws), self.nbytes * self.tries,
+                                                 _stream()), 'nif_kmeans_repair_kf_batch')
+        return changed
 
     def repair_kf(self, assign, nearest, prev):
         """In-place KF empty-cluster repair; returns the 0-d device flag (assign != prev).any()."""

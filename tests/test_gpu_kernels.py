@@ -605,6 +605,29 @@ def test_kmeans_farthest_init_many_equals_one_by_one(ops, N, k, T, gdtype):
         assert torch.equal(picks[t], p1) and torch.equal(assign[t], a1), (t, first)
 
 
+@pytest.mark.parametrize('gdtype', [torch.float64, torch.float32])
+def test_kmeans_batched_tries_equal_one_by_one(ops, gdtype):
+    """lloyd_step_many / repair_kf_many over a subset of tries: the rows of the single-problem calls, bit for bit."""
+    N, k, m, T = 700, 90, 48, 5
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(m, N, generator=g)
+    s = (torch.rand(N, generator=g) + 0.2).cuda()
+    G64, _, _ = ops.xty(A.double().cuda(), None, acc='f64', norms=False)
+    G, nn = G64.to(gdtype), torch.diagonal(G64).contiguous()
+    assign = torch.randint(0, k - 3, (T, N), generator=g).int().cuda()  # the top labels are empty: repair has work
+    many = ops.KMeans(G, nn, s, k, gdiag=nn, tries=T)
+    live = [0, 2, 3]
+    out, nearest, cost, kp = many.lloyd_step_many(assign, live)
+    pre = out.clone()
+    changed = many.repair_kf_many(out, nearest, assign, live)
+    one = ops.KMeans(G, nn, s, k, gdiag=nn)
+    for t in live:
+        o1, n1, c1, k1 = one.lloyd_step(assign[t].contiguous())
+        assert torch.equal(pre[t], o1) and torch.equal(cost[t], c1) and int(kp[t]) == int(k1)
+        ch1 = one.repair_kf(o1, n1, assign[t].contiguous())
+        assert torch.equal(out[t], o1) and torch.equal(nearest[t], n1) and int(changed[t]) == int(ch1)
+
+
 def test_kmeans_centroid_weights_and_repair(ops):
     N, k, d = 40, 9, 17
     g = torch.Generator().manual_seed(2)
