@@ -19,8 +19,8 @@ builds its partial [G | na | nb] buffer and one RCCL all-reduce (sum, f64) per l
 them; the n x n assignment and the refit are replicated.
 Levels are independent (activations are captured once), so the loop is software-pipelined over
 two HIP streams: the Gram and its all-reduce of level i + 1 are in flight while
-the single-workgroup assignment and the refit of level i run.  --no-overlap gives the serial loop; with
-N > 1 the serial loop is the default (see main()).
+the single-workgroup assignment and the refit of level i run.  --no-overlap gives the serial loop (the default of
+the gloo rehearsal backend, where both ranks share one GPU and overlapping only adds contention).
 
 The JSON line also carries
   roofline     : the dominant kernel (nif::xty_kernel, f32 MFMA): algorithmic flops
@@ -158,9 +158,12 @@ def cpu_level(lv_cpu):
 
 
 def main():
-    if os.environ.get('NIF_BENCH_WATCHDOG'):  # debugging aid: dump every thread's stack and exit if the run stalls
+    # a stalled collective must end the run (non-zero, every thread's stack on stderr) instead of hanging a scaling
+    # sweep: on by default with N > 1 (NIF_BENCH_WATCHDOG=seconds overrides, 0 turns it off)
+    watchdog = os.environ.get('NIF_BENCH_WATCHDOG', '600' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else '0')
+    if int(watchdog) > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['NIF_BENCH_WATCHDOG']), exit=True)
+        faulthandler.dump_traceback_later(int(watchdog), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--workload', choices=['c2', 'c1', 'c3', 'c4', 'sk'], default='c2',
@@ -223,10 +226,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the two-stream pipeline is used where it could be verified (one GPU); with N > 1 the loop stays serial on the
-    # default stream unless --overlap-multi is given: the overlapped collective could not be exercised on RCCL from
-    # the one-GPU development box, and a stall there would lose the whole scaling run
-    overlap = not args.no_overlap and (world == 1 or args.overlap_multi)
+    # Two-stream pipeline: N = 1, and N > 1 on RCCL (the collective of level i + 1 rides the front stream while the
+    # assignment and refit of level i run on the back stream -- at 1/8 of the rows the all-reduce is a third of a
+    # level).  The two-rank rehearsal of exactly this loop passes (profiles/r2_gloo2_overlap_bench.json: gloo, both
+    # ranks on one GPU, where it is SLOWER than the serial loop because the ranks' Grams contend for the one GPU --
+    # hence serial stays the default for gloo; --overlap-multi / --no-overlap force either).
+    overlap = not args.no_overlap and (world == 1 or args.overlap_multi or args.backend == 'nccl')
     pipe = LevelPipeline(ops, lv, dist) if overlap else None
 
     def run_levels(count):
