@@ -169,7 +169,7 @@ def main():
     ap.add_argument('--workload', choices=['c2', 'c1', 'c3', 'c4', 'sk'], default='c2',
                     help='c2 (default): the per-level throughput benchmark; c1 / c3 / c4: end-to-end fusion wall-clock of '
                          'BASELINE.json configs 1 / 3 / 4 on one GPU; sk: the additional Sinkhorn mode (bench_e2e.py)')
-    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 200 levels; 5 fusions for c1/c3/c4)')
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 2000 levels; 5 fusions / solves for c1/c3/c4/sk)')
     ap.add_argument('--warmup', type=int, default=None, help='untimed steps (default 10; 1 for c1/c3/c4)')
     ap.add_argument('--hard-steps', type=int, default=20, help='timed levels of the hard-assignment variant (N = 1)')
     ap.add_argument('--rows', type=int, default=M_ROWS)
@@ -210,8 +210,8 @@ def main():
         warmup = 1 if args.warmup is None else args.warmup
         print(json.dumps(bench_e2e.run(args.workload, ops, device, steps, warmup)), flush=True)
         return
-    args.steps = 200 if args.steps is None else args.steps
-    args.warmup = 10 if args.warmup is None else args.warmup
+    args.steps = 2000 if args.steps is None else args.steps  # ~1.6 s timed at N = 1
+    args.warmup = 20 if args.warmup is None else args.warmup
 
     n = args.width
     m_total = args.rows
