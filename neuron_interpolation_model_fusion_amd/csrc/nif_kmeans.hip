@@ -433,20 +433,32 @@ __global__ __launch_bounds__(256) void kmeans_members_kernel(const int* __restri
   }
 }
 
-// S[cc] = sum of the member weights of cluster c, in member order (one lane per cluster)
-__global__ void kmeans_S_kernel(const float* __restrict__ s, const int* __restrict__ order, const int* __restrict__ seg,
-                                const int* __restrict__ compact, int k, double* __restrict__ S, KmBatch kb) {
+// S[cc] = sum of the member weights of cluster c, added one by one in member order.  One WAVE per cluster: the lanes
+// fetch 64 members at a time (one dependent load chain per 64 members instead of per member -- a cluster that has
+// swallowed half a wide layer took 6 ms with one lane per cluster), then the values are added in lane order.
+__global__ __launch_bounds__(256) void kmeans_S_kernel(const float* __restrict__ s, const int* __restrict__ order,
+                                                       const int* __restrict__ seg, const int* __restrict__ compact,
+                                                       int k, double* __restrict__ S, KmBatch kb) {
   order = kb_ws(order, kb);
   seg = kb_ws(seg, kb);
   compact = kb_ws(compact, kb);
   S = kb_ws(S, kb);
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= k) return;
   const int cc = compact[c];
   if (cc < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int b = seg[c], e = seg[c + 1];
   double tot = 0.0;
-  for (int t = seg[c]; t < seg[c + 1]; ++t) tot += (double)s[order[t]];
-  S[cc] = tot;
+  for (int t0 = b; t0 < e; t0 += 64) {
+    const int t = t0 + lane;
+    const double val = t < e ? (double)s[order[t]] : 0.0;  // padding adds an exact +0 (tot never holds -0)
+    const int lo = __double2loint(val), hi = __double2hiint(val);
+#pragma unroll
+    for (int l = 0; l < 64; ++l)
+      tot += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+  }
+  if (lane == 0) S[cc] = tot;
 }
 
 // cost = sum of the per-block partials: lane l adds partial[l], partial[l + 64], ... in order, then a fixed tree
@@ -483,7 +495,20 @@ __global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const
   const int i = order[t];
   const int c = assign[i];
   double acc = 0.0;
-  for (int u = seg[c]; u < seg[c + 1]; ++u) {
+  int u = seg[c];
+  const int ue = seg[c + 1];
+  for (; u + 8 <= ue; u += 8) {  // eight independent loads in flight, added in member order
+    double g[8], w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int ip = order[u + q];
+      w[q] = (double)s[ip];
+      g[q] = gram_at(G + (int64_t)ip * ldg, ip, i, gd);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += w[q] * g[q];
+  }
+  for (; u < ue; ++u) {
     const int ip = order[u];
     acc += (double)s[ip] * gram_at(G + (int64_t)ip * ldg, ip, i, gd);
   }
@@ -1169,7 +1194,7 @@ static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const doubl
   float* ssorted = reinterpret_cast<float*>(b + w.off_wsorted);
   const int nb64 = (N + 63) / 64;
   km_group(assign, N, k, w, b, kprime, st, kb, L);
-  hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256, L), dim3(256), 0, st, s, order, seg, compact, k, S, kb);
+  hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 3) / 4, L), dim3(256), 0, st, s, order, seg, compact, k, S, kb);
   hipLaunchKernelGGL(kmeans_ssorted_kernel, dim3(w.nblk, L), dim3(256), 0, st, s, order, N, ssorted, kb);
   hipLaunchKernelGGL(kmeans_hself_kernel<GT>, dim3(w.nblk, L), dim3(256), 0, st, G, ldg, gd, s, order, assign, seg, compact,
                      S, N, hself, kb);
@@ -1335,7 +1360,7 @@ extern "C" int nif_kmeans_targets(const float* A, int64_t lda, int64_t m, const 
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kmeans_targets_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
-    hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 255) / 256), dim3(256), 0, st, w, order, seg, compact, k, S, km_single());
+    hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 3) / 4), dim3(256), 0, st, w, order, seg, compact, k, S, km_single());
     int64_t blocks = (m + R - 1) / R;
     if (blocks > 4096) blocks = 4096;
     const bool vec = (N % 4 == 0) && (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
