@@ -343,64 +343,93 @@ __global__ void kmeans_assign_to_neurons_kernel(const GT* __restrict__ G, int64_
 }
 
 // ---- Lloyd step -----------------------------------------------------------------------------------
+// clusters above KM_BIG members are summed in a chunked order (see "clusters that have swallowed ..." below)
+constexpr int KM_BIG = 1024;      // members
+constexpr int KM_BIG_MAX = 64;    // big clusters at most (the rest, if a layer had more, keep the sequential order)
+static inline int km_big_slots(int N) { return N / (KM_BIG + 1) < KM_BIG_MAX ? N / (KM_BIG + 1) : KM_BIG_MAX; }
 
 // counts[label]++ (counts zeroed by the caller)
 __global__ void kmeans_count_kernel(const int* __restrict__ assign, int N, int* __restrict__ counts, KmBatch kb) {
   assign = kb_row(assign, kb, N);
   counts = kb_ws(counts, kb);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) atomicAdd(&counts[assign[i]], 1);
+  const int lab = i < N ? assign[i] : -1;
+  // the lanes that share the first lane's label add once together: with one label on most of a layer the plain
+  // per-lane atomics all hit one address (0.27 ms for 24 576 neurons)
+  const int lead = __builtin_amdgcn_readfirstlane(lab);
+  const unsigned long long m = __ballot(lab == lead);
+  if (lab < 0) return;
+  if (lab != lead) atomicAdd(&counts[lab], 1);
+  else if ((threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&counts[lab], __popcll(m));
 }
 
 // seg = exclusive scan of counts; compact[c] = index of cluster c among the non-empty ones (or -1);
 // *kprime = number of non-empty clusters.  One workgroup: lane t owns a run of consecutive clusters.
 __global__ __launch_bounds__(1024) void kmeans_scan_kernel(const int* __restrict__ counts, int k,
                                                            int* __restrict__ seg, int* __restrict__ compact,
-                                                           int* __restrict__ kprime, KmBatch kb) {
+                                                           int* __restrict__ kprime, int big_slots,
+                                                           int* __restrict__ bigflag, int* __restrict__ biglist,
+                                                           KmBatch kb) {
+  bigflag = kb_ws(bigflag, kb);
+  biglist = kb_ws(biglist, kb);
   counts = kb_ws(counts, kb);
   seg = kb_ws(seg, kb);
   compact = kb_ws(compact, kb);
   kprime = kb_row(kprime, kb, 1);
-  __shared__ int wsum[16], wlive[16];
+  __shared__ int wsum[16], wlive[16], wbig[16];
   const int per = (k + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(lo + per, k);
-  int sum = 0, live = 0;
+  int sum = 0, live = 0, big = 0;
   for (int c = lo; c < hi; ++c) {
     const int n = counts[c];
     sum += n;
     live += n > 0 ? 1 : 0;
+    big += n > KM_BIG ? 1 : 0;
   }
   // inclusive scan inside the wave, then over the 16 wave totals
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int isum = sum, ilive = live;
+  int isum = sum, ilive = live, ibig = big;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const int a = __shfl_up(isum, o, 64), b = __shfl_up(ilive, o, 64);
+    const int a = __shfl_up(isum, o, 64), b = __shfl_up(ilive, o, 64), g = __shfl_up(ibig, o, 64);
     if (lane >= o) {
       isum += a;
       ilive += b;
+      ibig += g;
     }
   }
   if (lane == 63) {
     wsum[wave] = isum;
     wlive[wave] = ilive;
+    wbig[wave] = ibig;
   }
   __syncthreads();
-  int bsum = 0, blive = 0;
+  int bsum = 0, blive = 0, bbig = 0;
   for (int w = 0; w < wave; ++w) {
     bsum += wsum[w];
     blive += wlive[w];
+    bbig += wbig[w];
   }
-  int run = bsum + isum - sum, lv = blive + ilive - live;
+  int run = bsum + isum - sum, lv = blive + ilive - live, bg = bbig + ibig - big;
   for (int c = lo; c < hi; ++c) {
     const int n = counts[c];
     seg[c] = run;
     run += n;
     compact[c] = n > 0 ? lv++ : -1;
+    int slot = -1;
+    if (n > KM_BIG) {
+      if (bg < big_slots) {
+        slot = bg;
+        biglist[1 + slot] = c;
+      }
+      ++bg;
+    }
+    bigflag[c] = slot;
   }
   if (threadIdx.x == 1023) {
     seg[k] = run;
     *kprime = lv;
+    biglist[0] = min(bg, big_slots);
   }
 }
 
@@ -450,6 +479,12 @@ __global__ __launch_bounds__(256) void kmeans_S_kernel(const float* __restrict__
   const int lane = threadIdx.x & 63;
   const int b = seg[c], e = seg[c + 1];
   double tot = 0.0;
+  if (e - b > KM_BIG) {  // big cluster: lane-strided partial sums, then the fixed tree
+    for (int t = b + lane; t < e; t += 64) tot += (double)s[order[t]];
+    tot = wave_sum_f64(tot);
+    if (lane == 0) S[cc] = tot;
+    return;
+  }
   for (int t0 = b; t0 < e; t0 += 64) {
     const int t = t0 + lane;
     const double val = t < e ? (double)s[order[t]] : 0.0;  // padding adds an exact +0 (tot never holds -0)
@@ -478,12 +513,117 @@ __global__ __launch_bounds__(64) void kmeans_cost_kernel(const double* __restric
 // neuron.  So: hself[i] = H[c(i)][i] first, the norms from it, then ONE pass over G that forms every H[c][j] in
 // registers, turns it into a distance and keeps the minimum: 8 N^2 (f64 G) or 4 N^2 (f32 G) bytes per step.  (The
 // first version of this file wrote H and read it back, 16 k N bytes more; this pass gives the same bits.)
+// ---- clusters that have swallowed a large part of a layer --------------------------------------------------
+// Every sum over a cluster's members above runs in member order on one lane or wave: reproducible bit for bit, and
+// fine while clusters are small.  A cluster of n_c members costs n_c^2 sequential work in the in-cluster pass and one
+// wave's n_c-row walk in the main pass (a cluster holding half of a 24 576-neuron layer: 11 ms instead of 1 ms per
+// step).  Clusters above KM_BIG members therefore take a chunked order, still fixed and deterministic: members in
+// chunks of 64, chunk sums combined in chunk order.  Below the threshold nothing changes.
+
+// kmeans_scan_kernel numbers them: bigflag[c] = slot of cluster c (or -1), biglist[0] = count, biglist[1 + slot] = c.
+//
+// bigtot[slot][j] = sum over the members i of the big cluster of s_i G[i][j], for every neuron j.  Block = 64 neurons
+// x 16 waves as in the main pass; wave y walks the member chunks y, y + 16, ... (64 rows each) and the 16 partial
+// sums are added in wave order.  The main pass reads its distances to the big clusters from here, and the clusters'
+// norms come from the same numbers (|centroid|^2 S^2 = sum over members j of s_j bigtot[j]), so G's rows of a big
+// cluster are read once per step.
+template <typename GT>
+__global__ __launch_bounds__(1024) void kmeans_bigtot_kernel(const GT* __restrict__ G, int64_t ldg,
+                                                             const double* __restrict__ gd,
+                                                             const float* __restrict__ ssorted,
+                                                             const int* __restrict__ order, const int* __restrict__ seg,
+                                                             const int* __restrict__ biglist, int N,
+                                                             double* __restrict__ bigtot, KmBatch kb) {
+  ssorted = kb_ws(ssorted, kb);
+  order = kb_ws(order, kb);
+  seg = kb_ws(seg, kb);
+  biglist = kb_ws(biglist, kb);
+  bigtot = kb_ws(bigtot, kb);
+  const int nbig = biglist[0];
+  if (nbig == 0) return;
+  __shared__ double part[16][64];
+  const int tx = threadIdx.x & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * 64 + tx;
+  const int jc = j < N ? j : N - 1;
+  const double gjj = sizeof(GT) == 4 ? gd[jc] : 0.0;
+  const GT* __restrict__ col = G + jc;
+  for (int bb = 0; bb < nbig; ++bb) {  // uniform over the block
+    const int c = biglist[1 + bb];
+    const int b = seg[c], e = seg[c + 1];
+    double acc = 0.0;
+    for (int t0 = b + 64 * ty; t0 < e; t0 += 64 * 16) {
+      const int t1 = min(e, t0 + 64);
+      int t = t0;
+      for (; t + 8 <= t1; t += 8) {
+        double g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = order[t + u];
+          const double gv = (double)col[(int64_t)i * ldg];
+          g[u] = (sizeof(GT) == 4 && i == jc) ? gjj : gv;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)ssorted[t + u] * g[u];
+      }
+      for (; t < t1; ++t) {
+        const int i = order[t];
+        const double gv = (double)col[(int64_t)i * ldg];
+        acc += (double)ssorted[t] * ((sizeof(GT) == 4 && i == jc) ? gjj : gv);
+      }
+    }
+    __syncthreads();  // part is reused by every big cluster
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && j < N) {
+      double tot = 0.0;
+#pragma unroll
+      for (int y = 0; y < 16; ++y) tot += part[y][tx];
+      bigtot[(size_t)bb * N + j] = tot;
+    }
+  }
+}
+
+// cn of the big clusters: block = one slot; thread-strided partial sums over the members, then a fixed tree
+__global__ __launch_bounds__(256) void kmeans_cn_big_kernel(const double* __restrict__ bigtot, int N,
+                                                            const float* __restrict__ ssorted,
+                                                            const int* __restrict__ order, const int* __restrict__ seg,
+                                                            const int* __restrict__ compact,
+                                                            const int* __restrict__ biglist,
+                                                            const double* __restrict__ S, double* __restrict__ cn,
+                                                            KmBatch kb) {
+  bigtot = kb_ws(bigtot, kb);
+  ssorted = kb_ws(ssorted, kb);
+  order = kb_ws(order, kb);
+  seg = kb_ws(seg, kb);
+  compact = kb_ws(compact, kb);
+  biglist = kb_ws(biglist, kb);
+  S = kb_ws(S, kb);
+  cn = kb_ws(cn, kb);
+  const int slot = blockIdx.x;
+  if (slot >= biglist[0]) return;
+  __shared__ double wsum[4];
+  const int c = biglist[1 + slot];
+  const double* __restrict__ tot = bigtot + (size_t)slot * N;
+  double acc = 0.0;
+  for (int t = seg[c] + threadIdx.x; t < seg[c + 1]; t += 256) acc += (double)ssorted[t] * tot[order[t]];
+  acc = wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int cc = compact[c];
+    cn[cc] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / S[cc] / S[cc];
+  }
+}
+
 template <typename GT>
 __global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
                                     const float* __restrict__ s,
                                     const int* __restrict__ order, const int* __restrict__ assign,
                                     const int* __restrict__ seg, const int* __restrict__ compact,
-                                    const double* __restrict__ S, int N, double* __restrict__ hself, KmBatch kb) {
+                                    const double* __restrict__ S, int N, double* __restrict__ hself,
+                                    const int* __restrict__ bigflag, KmBatch kb) {
+  bigflag = kb_ws(bigflag, kb);
   order = kb_ws(order, kb);
   seg = kb_ws(seg, kb);
   compact = kb_ws(compact, kb);
@@ -494,6 +634,7 @@ __global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const
   if (t >= N) return;
   const int i = order[t];
   const int c = assign[i];
+  if (bigflag[c] >= 0) return;  // big clusters get their norm from kmeans_bigtot_kernel's sums
   double acc = 0.0;
   int u = seg[c];
   const int ue = seg[c + 1];
@@ -519,7 +660,8 @@ __global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const
 __global__ void kmeans_cn_self_kernel(const double* __restrict__ hself, const float* __restrict__ s,
                                       const int* __restrict__ order, const int* __restrict__ seg,
                                       const int* __restrict__ compact, const double* __restrict__ S, int k,
-                                      double* __restrict__ cn, KmBatch kb) {
+                                      double* __restrict__ cn, const int* __restrict__ bigflag, KmBatch kb) {
+  bigflag = kb_ws(bigflag, kb);
   hself = kb_ws(hself, kb);
   order = kb_ws(order, kb);
   seg = kb_ws(seg, kb);
@@ -529,7 +671,7 @@ __global__ void kmeans_cn_self_kernel(const double* __restrict__ hself, const fl
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= k) return;
   const int cc = compact[c];
-  if (cc < 0) return;
+  if (cc < 0 || bigflag[c] >= 0) return;
   const int lane = threadIdx.x & 63;
   double acc = 0.0;
   for (int t = seg[c] + lane; t < seg[c + 1]; t += 64) {
@@ -559,7 +701,11 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
     const int* __restrict__ order, const int* __restrict__ seg, const int* __restrict__ compact,
     const double* __restrict__ S,
     const double* __restrict__ cn, const double* __restrict__ nn, const float* __restrict__ s, int N, int k,
-    int* __restrict__ assign_out, double* __restrict__ nearest, double* __restrict__ partial, KmBatch kb) {
+    int* __restrict__ assign_out, double* __restrict__ nearest, double* __restrict__ partial,
+    const int* __restrict__ bigflag, const int* __restrict__ biglist, const double* __restrict__ bigtot, KmBatch kb) {
+  bigflag = kb_ws(bigflag, kb);
+  biglist = kb_ws(biglist, kb);
+  bigtot = kb_ws(bigtot, kb);
   ssorted = kb_ws(ssorted, kb);
   order = kb_ws(order, kb);
   seg = kb_ws(seg, kb);
@@ -584,7 +730,7 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
   int bc = INT_MAX;
   for (int c = c_lo; c < c_hi; ++c) {
     const int cc = compact[c];
-    if (cc < 0) continue;
+    if (cc < 0 || bigflag[c] >= 0) continue;  // big clusters: from bigtot, below
     const int b = seg[c], e = seg[c + 1];
     double acc = 0.0;
     int t = b;
@@ -620,6 +766,15 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
     if (ov < best || (ov == best && oc < bc)) {
       best = ov;
       bc = oc;
+    }
+  }
+  const int nbig = biglist[0];
+  for (int bb = 0; bb < nbig; ++bb) {  // big clusters: their sums were formed by kmeans_bigtot_kernel
+    const int cc = compact[biglist[1 + bb]];
+    const double d2 = cn[cc] - 2.0 * (bigtot[(size_t)bb * N + jc] / S[cc]) + nj;
+    if (d2 < best || (d2 == best && cc < bc)) {
+      best = d2;
+      bc = cc;
     }
   }
   double contrib = 0.0;
@@ -1020,7 +1175,7 @@ static bool km_launch_sw(int64_t blocks, hipStream_t st, const float* A, int64_t
 }
 
 struct KmWs {
-  size_t off_rank, off_counts, off_seg, off_compact, off_order, off_wT, off_S, off_cn, off_partial, off_pos, off_wsorted, off_hself, total;
+  size_t off_rank, off_counts, off_seg, off_compact, off_order, off_wT, off_S, off_cn, off_partial, off_pos, off_wsorted, off_hself, off_bigflag, off_biglist, off_bigtot, total;
   int nblk;
 };
 static inline size_t ka(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1039,6 +1194,9 @@ static KmWs km_ws(int N, int k) {
   w.off_pos = o; o += ka((size_t)N * 4);
   w.off_wsorted = o; o += ka((size_t)N * 4);
   w.off_hself = o; o += ka((size_t)N * 8);
+  w.off_bigflag = o; o += ka((size_t)k * 4);
+  w.off_biglist = o; o += ka((size_t)(1 + KM_BIG_MAX) * 4);
+  w.off_bigtot = o; o += ka((size_t)km_big_slots(N) * N * 8);
   w.off_wT = o; o += ka((size_t)k * N * 4);  // member-major weights of nif_kmeans_targets: (largest cluster) x k
   w.total = o;
   return w;
@@ -1063,7 +1221,8 @@ static void km_group(const int* assign, int N, int k, const KmWs& w, unsigned ch
     (void)hipMemsetAsync(reinterpret_cast<unsigned char*>(counts) + (size_t)kb.idx[e] * (size_t)kb.ws_stride, 0,
                          (size_t)k * 4, st);
   hipLaunchKernelGGL(kmeans_count_kernel, dim3(w.nblk, L), dim3(256), 0, st, assign, N, counts, kb);
-  hipLaunchKernelGGL(kmeans_scan_kernel, dim3(1, L), dim3(1024), 0, st, counts, k, seg, compact, kprime, kb);
+  hipLaunchKernelGGL(kmeans_scan_kernel, dim3(1, L), dim3(1024), 0, st, counts, k, seg, compact, kprime, km_big_slots(N),
+                     reinterpret_cast<int*>(b + w.off_bigflag), reinterpret_cast<int*>(b + w.off_biglist), kb);
   hipLaunchKernelGGL(kmeans_members_kernel, dim3((k + 3) / 4, L), dim3(256), 0, st, assign, seg, N, k, order, kb);
 }
 
@@ -1196,13 +1355,22 @@ static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const doubl
   km_group(assign, N, k, w, b, kprime, st, kb, L);
   hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 3) / 4, L), dim3(256), 0, st, s, order, seg, compact, k, S, kb);
   hipLaunchKernelGGL(kmeans_ssorted_kernel, dim3(w.nblk, L), dim3(256), 0, st, s, order, N, ssorted, kb);
+  int* bigflag = reinterpret_cast<int*>(b + w.off_bigflag);
+  int* biglist = reinterpret_cast<int*>(b + w.off_biglist);
+  double* bigtot = reinterpret_cast<double*>(b + w.off_bigtot);
   hipLaunchKernelGGL(kmeans_hself_kernel<GT>, dim3(w.nblk, L), dim3(256), 0, st, G, ldg, gd, s, order, assign, seg, compact,
-                     S, N, hself, kb);
+                     S, N, hself, bigflag, kb);
   hipLaunchKernelGGL(kmeans_cn_self_kernel, dim3((k + 3) / 4, L), dim3(256), 0, st, hself, s, order, seg, compact, S, k, cn,
-                     kb);
+                     bigflag, kb);
+  if (km_big_slots(N) > 0) {  // both leave at once when the step has no big cluster
+    hipLaunchKernelGGL(kmeans_bigtot_kernel<GT>, dim3(nb64, L), dim3(1024), 0, st, G, ldg, gd, ssorted, order, seg, biglist,
+                       N, bigtot, kb);
+    hipLaunchKernelGGL(kmeans_cn_big_kernel, dim3(km_big_slots(N), L), dim3(256), 0, st, bigtot, N, ssorted, order, seg,
+                       compact, biglist, S, cn, kb);
+  }
   prof_begin(NIF_PROF_KMEANS, st);
   hipLaunchKernelGGL(kmeans_nearest_fused_kernel<GT>, dim3(nb64, L), dim3(1024), 0, st, G, ldg, gd, ssorted, order, seg,
-                     compact, S, cn, nn, s, N, k, assign_out, nearest, partial, kb);
+                     compact, S, cn, nn, s, N, k, assign_out, nearest, partial, bigflag, biglist, bigtot, kb);
   prof_end(NIF_PROF_KMEANS, st);
   hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1, L), dim3(64), 0, st, partial, nb64, cost, kb);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;

@@ -508,6 +508,43 @@ def test_kmeans_lloyd_step_matches_f64_reference(ops, N, k, m, empty):
     np.testing.assert_allclose(float(cost), c, rtol=1e-9)
 
 
+@pytest.mark.parametrize('N,k,m,sizes', [(6000, 40, 48, (3000,)), (9000, 64, 32, (1025, 4100, 1024)), (5000, 3, 24, (2500, 2400)),
+                                          (3000, 8, 16, (2993,))])
+def test_kmeans_lloyd_step_clusters_above_the_chunking_threshold(ops, N, k, m, sizes):
+    """Clusters of more than 1024 members take the chunked summation order (csrc/nif_kmeans.hip KM_BIG): same labels
+    and distances as the f64 reference, the same step twice gives the same bits, and a batch of tries equals one by one."""
+    A, s, assign = _kmeans_problem(N, k, m, N + 11 * k)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(N))
+    at = 0
+    assert len(sizes) < k
+    for c, n_c in enumerate(sizes):  # label c + 1 takes n_c neurons, scattered over the layer
+        assign[perm[at:at + n_c]] = c + 1
+        at += n_c
+    assert 0 <= int(assign.min()) and int(assign.max()) < k
+    G, _, _ = ops.xty(A.double().cuda(), None, acc='f64', norms=False)
+    gd = torch.diagonal(G).contiguous()
+    arg, near, c_ref, kprime, _ = _ref_lloyd(A, s, assign, k)
+    for Gs in (G, G.float()):
+        km = ops.KMeans(Gs, gd, s.cuda(), k, gdiag=gd)
+        out, nearest, cost, kp = km.lloyd_step(assign.cuda())
+        out, nearest, cost = out.clone(), nearest.clone(), float(cost)
+        assert int(kp) == kprime
+        assert (out.cpu().long() == arg).all()
+        tol = dict(rtol=1e-7, atol=2e-6) if Gs.dtype == torch.float64 else dict(rtol=4e-6, atol=4e-5)
+        np.testing.assert_allclose(nearest.cpu().numpy(), near.numpy(), **tol)
+        np.testing.assert_allclose(cost, c_ref, rtol=1e-9 if Gs.dtype == torch.float64 else 2e-6)
+        out2, nearest2, cost2, _ = km.lloyd_step(assign.cuda())
+        assert torch.equal(out2, out) and torch.equal(nearest2, nearest) and float(cost2) == cost
+        # two tries in one launch: the skewed assignment beside a balanced one
+        other = _kmeans_problem(N, k, m, 5)[2]
+        kmb = ops.KMeans(Gs, gd, s.cuda(), k, gdiag=gd, tries=2)
+        both = torch.stack([assign, other]).cuda()
+        res = kmb.lloyd_step_many(both, [0, 1])
+        assert torch.equal(res[0][0], out) and torch.equal(res[1][0], nearest) and float(res[2][0]) == cost
+        o1 = km.lloyd_step(other.cuda())
+        assert torch.equal(res[0][1], o1[0]) and torch.equal(res[1][1], o1[1])
+
+
 @pytest.mark.parametrize('N,k,m', [(50, 7, 33), (771, 100, 20), (4096, 512, 70), (20000, 96, 9), (40001, 12, 5)])
 def test_kmeans_targets_all_staging_variants(ops, N, k, m):
     """LDS-staged rows (several rows per block, one wide row per block, unaligned width) and the gather fallback."""
