@@ -12,9 +12,10 @@
 //   3. Eigenvectors of the KEPT eigenvalues by inverse iteration (LU with partial pivoting of T - lambda I, one lane
 //      per eigenvector, lanes in lock step over the rows, factors stored [row][vector] for coalescing), distinct
 //      pseudo-random starts, modified Gram-Schmidt inside groups of eigenvalues closer than 1e-9 |T|.
-//   4. Back-transformation by blocks of 64 reflectors without forming T: (I - V T V^T) Z = Z - V Y with
-//      (diag(1/tau) + striu(V^T V)) Y = V^T Z; the two products with the long contraction run on the f64 matrix
-//      cores (nif_xty), the triangular solve and the rank-64 update are small dedicated kernels.
+//   4. Back-transformation by blocks of 64 reflectors: (I - V T V^T) Z = Z - (V T) (V^T Z) with
+//      T = (diag(1/tau) + striu(V^T V))^-1.  V, T and V T of every block are prepared by four batched launches; the
+//      chain over the blocks is then one product with the long contraction on the f64 matrix cores (nif_xty) and
+//      one rank-64 update per block.
 //
 // Everything is f64.  The entry point synchronises the stream ONCE (after step 2) to learn how many eigenpairs are
 // kept: that count is an output and sizes the launches of steps 3-4.
@@ -607,8 +608,20 @@ __global__ __launch_bounds__(ORT_T) void tri_ortho_kernel(const double* __restri
 }
 
 // ---- back-transformation Z <- H_0 H_1 ... H_{n-3} Z -------------------------------------------------------------
-// Vb[(r - (j0 + 1))][l] = reflector j0 + l at row r, rows j0+1 .. n-1 (nr rows), nb columns (zero beyond nbk)
-__global__ void bt_extract_kernel(const double* __restrict__ A, int64_t ld, int n, int j0, int nbk, double* __restrict__ Vb) {
+// Block bi holds the reflectors j0 = 64 bi ... and touches the rows j0+1 .. n-1 (nr = n - 1 - j0 of them).  Everything
+// about a block that does not depend on Z -- its reflectors gathered into a dense nr x 64 panel V, the triangular factor
+// T of I - V T V^T, and the product V T -- is prepared for ALL blocks by four launches before the chain over the blocks
+// starts, so the chain itself is two steps per block: M = V^T Z (matrix cores) and Z -= (V T) M.  (The first version
+// ran seven dependent launches per block, two of them single-wave triangular kernels of 34 and 42 us.)
+// The panels of the blocks lie one after the other: block bi starts at row bt_rows_before(n, bi).
+__host__ __device__ inline size_t bt_rows_before(int n, int bi) {
+  return (size_t)bi * (size_t)(n - 1) - (size_t)EIG_NB * (size_t)bi * (size_t)(bi > 0 ? bi - 1 : 0) / 2;
+}
+
+// Vall: panel bi, [(r - (j0 + 1))][l] = reflector j0 + l at row r (zero beyond the nbk reflectors of the last block)
+__global__ void bt_extract_kernel(const double* __restrict__ A, int64_t ld, int n, int nref, double* __restrict__ Vall) {
+  const int bi = blockIdx.y, j0 = bi * EIG_NB;
+  const int nbk = nref - j0 < EIG_NB ? nref - j0 : EIG_NB;
   const int l = threadIdx.x & (EIG_NB - 1);
   const int rr = blockIdx.x * (256 / EIG_NB) + (threadIdx.x / EIG_NB);
   const int nr = n - (j0 + 1);
@@ -619,22 +632,75 @@ __global__ void bt_extract_kernel(const double* __restrict__ A, int64_t ld, int 
     if (r == j + 1) v = 1.0;
     else if (r >= j + 2) v = A[(size_t)r * ld + j];
   }
-  Vb[(size_t)rr * EIG_NB + l] = v;
+  Vall[(bt_rows_before(n, bi) + rr) * EIG_NB + l] = v;
 }
 
-// T = (diag(1/tau) + striu(S))^-1, the triangular factor of the block reflector I - V T V^T.  Thread c owns column c
+// Spart[bi][s] = (rows s * BT_RC ... of panel bi)^T (the same rows): 64 x 64, 256 threads, 4 x 4 per thread
+constexpr int BT_RC = 512;
+__global__ __launch_bounds__(256) void bt_gram_kernel(const double* __restrict__ Vall, int n, int splits,
+                                                      double* __restrict__ Spart) {
+  __shared__ double sV[32][EIG_NB + 2];
+  const int bi = blockIdx.y, sp = blockIdx.x, tid = threadIdx.x;
+  const int nr = n - 1 - bi * EIG_NB;
+  const int r0 = sp * BT_RC;
+  if (r0 >= nr) return;  // uniform; the factor kernel only adds the splits that exist
+  const int rend = nr < r0 + BT_RC ? nr : r0 + BT_RC;
+  const double* __restrict__ Vb = Vall + bt_rows_before(n, bi) * EIG_NB;
+  const int ti = (tid / 16) * 4, tj = (tid % 16) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) acc[i][k2] = 0.0;
+  for (int rc = r0; rc < rend; rc += 32) {
+    __syncthreads();
+    for (int q = tid; q < 32 * EIG_NB; q += 256) {
+      const int rr = rc + q / EIG_NB;
+      sV[q / EIG_NB][q % EIG_NB] = rr < rend ? Vb[(size_t)rr * EIG_NB + q % EIG_NB] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      double x[4], y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = sV[r][ti + i];
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) y[k2] = sV[r][tj + k2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) acc[i][k2] += x[i] * y[k2];
+    }
+  }
+  double* __restrict__ out = Spart + ((size_t)bi * splits + sp) * (EIG_NB * EIG_NB);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) out[(ti + i) * EIG_NB + tj + k2] = acc[i][k2];
+}
+
+// T = (diag(1/tau) + striu(S))^-1, the triangular factor of the block reflector I - V T V^T; one wave per block of
+// reflectors.  S is the sum of the block's partial Grams, added in split order.  Thread c owns column c
 // of T in registers (fully unrolled back substitution, entries below the diagonal stay zero), every thread walks the
 // same (i, l) sequence so S[i][l] is one LDS broadcast.  tau = 0 (identity reflector) gives a zero row and column.
-__global__ __launch_bounds__(64) void bt_tfactor_kernel(const double* __restrict__ S, int64_t lds_,
-                                                        const double* __restrict__ tau, int nbk, double* __restrict__ T) {
+__global__ __launch_bounds__(64) void bt_tfactor_kernel(const double* __restrict__ Spart, int splits, int n, int nref,
+                                                        const double* __restrict__ tau_all, double* __restrict__ Tall) {
   __shared__ __attribute__((aligned(16))) double sS[EIG_NB][EIG_NB];
   __shared__ double st[EIG_NB];
+  const int bi = blockIdx.x, j0 = bi * EIG_NB;
+  const int nbk = nref - j0 < EIG_NB ? nref - j0 : EIG_NB;
+  const int nsp = (n - 1 - j0 + BT_RC - 1) / BT_RC;
+  const double* __restrict__ S = Spart + (size_t)bi * splits * (EIG_NB * EIG_NB);
+  double* __restrict__ T = Tall + (size_t)bi * (EIG_NB * EIG_NB);
   const int c = threadIdx.x;
   for (int q = c; q < EIG_NB * EIG_NB; q += 64) {
     const int i = q / EIG_NB, l = q % EIG_NB;
-    sS[i][l] = (i < nbk && l < nbk) ? S[(size_t)i * lds_ + l] : 0.0;
+    double v = 0.0;
+    if (i < nbk && l < nbk)
+      for (int sp = 0; sp < nsp; ++sp) v += S[(size_t)sp * (EIG_NB * EIG_NB) + q];
+    sS[i][l] = v;
   }
-  st[c] = c < nbk ? tau[c] : 0.0;
+  st[c] = c < nbk ? tau_all[j0 + c] : 0.0;
   __syncthreads();
   double t[EIG_NB];
 #pragma unroll
@@ -651,37 +717,15 @@ __global__ __launch_bounds__(64) void bt_tfactor_kernel(const double* __restrict
   for (int l = 0; l < EIG_NB; ++l) T[(size_t)l * EIG_NB + c] = t[l];
 }
 
-// Y = T M in place (T upper triangular EIG_NB x EIG_NB, M: EIG_NB x K with rows >= nbk treated as zero): thread per
-// column of M, the column in registers, T[i][l] an LDS broadcast.
-__global__ __launch_bounds__(64) void bt_tm_kernel(const double* __restrict__ T, int nbk, double* __restrict__ M,
-                                                   int64_t ldm, int K) {
-  __shared__ __attribute__((aligned(16))) double sT[EIG_NB][EIG_NB];
-  for (int q = threadIdx.x; q < EIG_NB * EIG_NB; q += 64) sT[q / EIG_NB][q % EIG_NB] = T[q];
-  __syncthreads();
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= K) return;
-  double m[EIG_NB];
-#pragma unroll
-  for (int l = 0; l < EIG_NB; ++l) m[l] = l < nbk ? M[(size_t)l * ldm + c] : 0.0;
-#pragma unroll
-  for (int i = 0; i < EIG_NB; ++i) {
-    double y = 0.0;
-#pragma unroll
-    for (int l = i; l < EIG_NB; ++l) y += sT[i][l] * m[l];
-    if (i < nbk) M[(size_t)i * ldm + c] = y;
-  }
-}
-
-// Z[j0+1+rr][c] -= sum_l Vb[rr][l] Y[l][c]: 64 x 64 tiles, 256 threads, 4 x 4 per thread, l in two halves of 32
-__global__ __launch_bounds__(256) void bt_update_kernel(const double* __restrict__ Vb, const double* __restrict__ Y,
-                                                        int64_t ldy, int nr, int nbk, int K, double* __restrict__ Zs,
-                                                        int64_t ldz) {
+// acc = (rows r0 .. r0+63 of Vb) (columns cb .. cb+63 of Y): 64 x 64 tile, 256 threads, 4 x 4 per thread, l in two
+// halves of 32
+__device__ __forceinline__ void bt_tile(const double* __restrict__ Vb, const double* __restrict__ Y, int64_t ldy, int nr,
+                                        int nbk, int K, int r0, int cb, double (&acc)[4][4]) {
   constexpr int LH = 32;
   __shared__ double sV[64][LH + 1];
   __shared__ double sY[LH][64 + 2];
-  const int r0 = blockIdx.y * 64, cb = blockIdx.x * 64, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
-  double acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -710,6 +754,16 @@ __global__ __launch_bounds__(256) void bt_update_kernel(const double* __restrict
         for (int k2 = 0; k2 < 4; ++k2) acc[i][k2] += v[i] * y[k2];
     }
   }
+}
+
+// Z[j0+1+rr][c] -= sum_l VT[rr][l] M[l][c]
+__global__ __launch_bounds__(256) void bt_update_kernel(const double* __restrict__ VT, const double* __restrict__ M,
+                                                        int64_t ldm, int nr, int nbk, int K, double* __restrict__ Zs,
+                                                        int64_t ldz) {
+  const int r0 = blockIdx.y * 64, cb = blockIdx.x * 64;
+  const int tr = (threadIdx.x / 16) * 4, tc = (threadIdx.x % 16) * 4;
+  double acc[4][4];
+  bt_tile(VT, M, ldm, nr, nbk, K, r0, cb, acc);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + tr + i;
@@ -719,6 +773,26 @@ __global__ __launch_bounds__(256) void bt_update_kernel(const double* __restrict
       const int c = cb + tc + k2;
       if (c < K) Zs[(size_t)r * ldz + c] -= acc[i][k2];
     }
+  }
+}
+
+// VTall panel bi = (Vall panel bi) T_bi, every block of reflectors in one launch
+__global__ __launch_bounds__(256) void bt_vt_kernel(const double* __restrict__ Vall, const double* __restrict__ Tall, int n,
+                                                    double* __restrict__ VTall) {
+  const int bi = blockIdx.y;
+  const int nr = n - 1 - bi * EIG_NB;
+  const int r0 = blockIdx.x * 64;
+  if (r0 >= nr) return;  // uniform over the workgroup
+  const size_t at = bt_rows_before(n, bi) * EIG_NB;
+  const int tr = (threadIdx.x / 16) * 4, tc = (threadIdx.x % 16) * 4;
+  double acc[4][4];
+  bt_tile(Vall + at, Tall + (size_t)bi * (EIG_NB * EIG_NB), EIG_NB, nr, EIG_NB, EIG_NB, r0, 0, acc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + tr + i;
+    if (r >= nr) continue;
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) VTall[at + (size_t)r * EIG_NB + tc + k2] = acc[i][k2];
   }
 }
 
@@ -738,7 +812,8 @@ static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct EighWs {
   size_t off_A, off_vbuf, off_ybuf, off_d, off_e, off_tau, off_lam, off_shift, off_params, off_kept;
-  size_t off_fac, off_pv, off_Vb, off_S, off_T, off_M, off_xty, total;
+  size_t off_fac, off_pv, off_Vall, off_VTall, off_Spart, off_Tall, off_M, off_xty, total;
+  int bt_blocks, bt_splits;
   int64_t ld, ldz;
   size_t xty_bytes;
 };
@@ -761,9 +836,13 @@ static EighWs eigh_ws(int n) {
   w.off_kept = take(64);
   w.off_fac = take(4 * (size_t)n * n * 8);   // inv, du, du2, dl for up to n kept vectors
   w.off_pv = take((size_t)n * n);
-  w.off_Vb = take((size_t)n * EIG_NB * 8);
-  w.off_S = take((size_t)EIG_NB * EIG_NB * 8);
-  w.off_T = take((size_t)EIG_NB * EIG_NB * 8);
+  w.bt_blocks = n > 2 ? (n - 2 + EIG_NB - 1) / EIG_NB : 0;
+  w.bt_splits = (n + BT_RC - 1) / BT_RC;
+  const size_t panel_bytes = bt_rows_before(n, w.bt_blocks) * EIG_NB * 8;   // ~ n^2 / 2 doubles
+  w.off_Vall = take(panel_bytes);
+  w.off_VTall = take(panel_bytes);
+  w.off_Spart = take((size_t)w.bt_blocks * w.bt_splits * EIG_NB * EIG_NB * 8);
+  w.off_Tall = take((size_t)w.bt_blocks * EIG_NB * EIG_NB * 8);
   w.off_M = take((size_t)EIG_NB * w.ldz * 8);
   // nif_xty workspace of the two products of a block (f64 path, 128-wide tiles): the split-K plan aims at no more
   // than 512 workgroups, so tiles x splits <= 512 slabs of 128 x 128 doubles (64 MiB) plus the norm partials
@@ -887,29 +966,31 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
 
   // 4. back-transformation, last block of reflectors first
   if (n > 2) {
-    double* Vb = reinterpret_cast<double*>(b + w.off_Vb);
-    double* S = reinterpret_cast<double*>(b + w.off_S);
+    double* Vall = reinterpret_cast<double*>(b + w.off_Vall);
+    double* VTall = reinterpret_cast<double*>(b + w.off_VTall);
+    double* Spart = reinterpret_cast<double*>(b + w.off_Spart);
+    double* Tall = reinterpret_cast<double*>(b + w.off_Tall);
     double* M = reinterpret_cast<double*>(b + w.off_M);
-    double* Tm = reinterpret_cast<double*>(b + w.off_T);
     void* xws = b + w.off_xty;
     const int nref = n - 2;
-    const int nblk = (nref + EIG_NB - 1) / EIG_NB;
+    const int nblk = w.bt_blocks;
+    // everything that does not depend on Z, for all blocks at once
+    hipLaunchKernelGGL(bt_extract_kernel, dim3((n + 3) / 4, nblk), dim3(256), 0, st, t.A, w.ld, n, nref, Vall);
+    hipLaunchKernelGGL(bt_gram_kernel, dim3(w.bt_splits, nblk), dim3(256), 0, st, Vall, n, w.bt_splits, Spart);
+    hipLaunchKernelGGL(bt_tfactor_kernel, dim3(nblk), dim3(64), 0, st, Spart, w.bt_splits, n, nref, t.tau, Tall);
+    hipLaunchKernelGGL(bt_vt_kernel, dim3((n + 63) / 64, nblk), dim3(256), 0, st, Vall, Tall, n, VTall);
+    if (!launch_ok()) return NIF_ERR_LAUNCH;
     for (int bi = nblk - 1; bi >= 0; --bi) {
       const int j0 = bi * EIG_NB;
       const int nbk = nref - j0 < EIG_NB ? nref - j0 : EIG_NB;
       const int nr = n - (j0 + 1);
-      hipLaunchKernelGGL(bt_extract_kernel, dim3((nr + 3) / 4), dim3(256), 0, st, t.A, w.ld, n, j0, nbk, Vb);
-      int rc = nif_xty(Vb, EIG_NB, Vb, EIG_NB, nr, nbk, nbk, NIF_F64, NIF_F64, NIF_SYMMETRIC, S, EIG_NB, nullptr, nullptr,
-                       xws, w.xty_bytes, stream);
-      if (rc != NIF_OK) return rc;
+      const size_t at = bt_rows_before(n, bi) * EIG_NB;
       double* Zs = V + (size_t)(j0 + 1) * ldv;
-      rc = nif_xty(Vb, EIG_NB, Zs, ldv, nr, nbk, K, NIF_F64, NIF_F64, 0, M, w.ldz, nullptr, nullptr, xws, w.xty_bytes,
-                   stream);
+      const int rc = nif_xty(Vall + at, EIG_NB, Zs, ldv, nr, nbk, K, NIF_F64, NIF_F64, 0, M, w.ldz, nullptr, nullptr, xws,
+                             w.xty_bytes, stream);
       if (rc != NIF_OK) return rc;
-      hipLaunchKernelGGL(bt_tfactor_kernel, dim3(1), dim3(64), 0, st, S, (int64_t)EIG_NB, t.tau + j0, nbk, Tm);
-      hipLaunchKernelGGL(bt_tm_kernel, dim3((K + 63) / 64), dim3(64), 0, st, Tm, nbk, M, w.ldz, K);
-      hipLaunchKernelGGL(bt_update_kernel, dim3((K + 63) / 64, (nr + 63) / 64), dim3(256), 0, st, Vb, M, w.ldz, nr, nbk, K,
-                         Zs, ldv);
+      hipLaunchKernelGGL(bt_update_kernel, dim3((K + 63) / 64, (nr + 63) / 64), dim3(256), 0, st, VTall + at, M, w.ldz, nr,
+                         nbk, K, Zs, ldv);
     }
   }
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
