@@ -428,38 +428,43 @@ __global__ __launch_bounds__(64) void tri_invit_kernel(InvitArgs a) {
   const int jj = blockIdx.x * INV_VPW + threadIdx.x;
   if (threadIdx.x >= INV_VPW || jj >= a.K) return;
   const int n = a.n;
-  const int64_t K = a.K;
+  // the factors of a wave's INV_VPW vectors lie together, row after row (128-byte pieces 128 bytes apart): a wave
+  // streams its own contiguous region instead of touching one line per row per array scattered over n x K
+  const size_t fb = (size_t)blockIdx.x * (size_t)n * INV_VPW + threadIdx.x;
+  auto fi = [fb](int i) { return fb + (size_t)i * INV_VPW; };
   const double lam = a.shifts[jj];
   const double tiny = DBL_EPSILON * a.params[0];
   auto guard = [tiny](double p) { return fabs(p) < tiny ? (p < 0.0 ? -tiny : tiny) : p; };
-  // factor T - lam I = P L U
+  // factor T - lam I = P L U.  Branch-free (one divide per row whichever way the pivot goes), rows in chunks of 8 so
+  // that the uniform loads of d and e are issued together instead of one scalar round trip per row.
   double ca = a.d[0] - lam, cb = n > 1 ? a.e[0] : 0.0;
-  for (int i = 0; i + 1 < n; ++i) {
-    const double c = a.e[i], nd = a.d[i + 1] - lam, ne = i + 2 < n ? a.e[i + 1] : 0.0;
+  auto factor_row = [&](int i, double c, double nd, double ne) {
     const bool swap = fabs(c) > fabs(ca);
-    double piv, u1, u2, l, na_, nb_;
-    if (!swap) {
-      piv = guard(ca);
-      const double r = 1.0 / piv;
-      l = c * r;
-      u1 = cb; u2 = 0.0;
-      na_ = nd - l * cb; nb_ = ne;
-      a.inv[i * K + jj] = r;
-    } else {
-      piv = c;
-      const double r = 1.0 / piv;
-      l = ca * r;
-      u1 = nd; u2 = ne;
-      na_ = cb - l * nd; nb_ = -l * ne;
-      a.inv[i * K + jj] = r;
-    }
-    a.du[i * K + jj] = u1;
-    a.du2[i * K + jj] = u2;
-    a.dl[i * K + jj] = l;
-    a.pv[i * K + jj] = swap ? 1 : 0;
+    const double piv = swap ? c : guard(ca);
+    const double r = 1.0 / piv;
+    const double l = (swap ? ca : c) * r;
+    a.inv[fi(i)] = r;
+    a.du[fi(i)] = swap ? nd : cb;
+    a.du2[fi(i)] = swap ? ne : 0.0;
+    a.dl[fi(i)] = l;
+    a.pv[fi(i)] = swap ? 1 : 0;
+    const double na_ = swap ? cb - l * nd : nd - l * cb;
+    const double nb_ = swap ? -l * ne : ne;
     ca = na_; cb = nb_;
+  };
+  {
+    int i = 0;
+    for (; i + 8 <= n - 1; i += 8) {
+      double dd[8], ee[9];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dd[k] = a.d[i + 1 + k]; ee[k] = a.e[i + k]; }
+      ee[8] = a.e[i + 8];  // index <= n - 1: inside the array; unused (zero) when row i + 7 is the last one
+#pragma unroll
+      for (int k = 0; k < 8; ++k) factor_row(i + k, ee[k], dd[k] - lam, i + k + 2 < n ? ee[k + 1] : 0.0);
+    }
+    for (; i + 1 < n; ++i) factor_row(i, a.e[i], a.d[i + 1] - lam, i + 2 < n ? a.e[i + 1] : 0.0);
   }
-  a.inv[(int64_t)(n - 1) * K + jj] = 1.0 / guard(ca);
+  a.inv[fi(n - 1)] = 1.0 / guard(ca);
   // start vector
   double* z = a.Z + jj;
   const int64_t ldz = a.ldz;
@@ -468,18 +473,22 @@ __global__ __launch_bounds__(64) void tri_invit_kernel(InvitArgs a) {
   // The solves are chains of dependent FMAs fed by strided loads; only a few dozen waves exist chip-wide, so nothing
   // hides a load's round trip except the wave itself: operands travel in chunks of CH rows, and the next chunk's
   // loads are always issued before the current chunk's chain runs (two register sets, loop unrolled by two).
+  // The main loops hold FULL chunks only and no branch: with a guard per row inside them the compiler can no longer
+  // count the loads in flight and waits for all of them (vmcnt(0)) before every chunk, which serialises the prefetch
+  // with the chain -- that version spent 190 ns per row, one memory round trip per 8 rows.  The ragged end runs
+  // through a guarded copy once per pass.
   constexpr int CH = 8;
   struct Fwd { double nxt[CH], l[CH]; unsigned char sw[CH]; };
   struct Bwd { double y[CH], u1[CH], u2[CH], r[CH]; };
-  auto load_f = [&](Fwd& f, int i0) {
+  auto load_f = [&](Fwd& f, int i0) {   // rows clamped into the matrix: callable past the end
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       int i = i0 + k;
       i = i < n - 1 ? i : n - 2;
       i = i < 0 ? 0 : i;
       f.nxt[k] = z[(int64_t)(i + 1 < n ? i + 1 : n - 1) * ldz];
-      f.l[k] = a.dl[i * K + jj];
-      f.sw[k] = a.pv[i * K + jj];
+      f.l[k] = a.dl[fi(i)];
+      f.sw[k] = a.pv[fi(i)];
     }
   };
   auto load_b = [&](Bwd& f, int i0) {
@@ -487,69 +496,94 @@ __global__ __launch_bounds__(64) void tri_invit_kernel(InvitArgs a) {
     for (int k = 0; k < CH; ++k) {
       const int i = i0 - k >= 0 ? i0 - k : 0;
       f.y[k] = z[(int64_t)i * ldz];
-      f.u1[k] = a.du[i * K + jj];
-      f.u2[k] = a.du2[i * K + jj];
-      f.r[k] = a.inv[i * K + jj];
+      f.u1[k] = a.du[fi(i)];
+      f.u2[k] = a.du2[fi(i)];
+      f.r[k] = a.inv[fi(i)];
     }
   };
   for (int it = 0; it < a.iters; ++it) {
+    // the previous solve's result is normalised as it is read (three unscaled solves can reach 1e48, more would
+    // overflow): no separate scaling pass between the iterations
+    const double sc = it == 0 ? 1.0 : 1.0 / sqrt(nrm2);
     // forward: y = L^-1 P x
-    double cur = z[0];
-    auto run_f = [&](const Fwd& f, int i0) {
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        if (i0 + k < n - 1) {
-          const bool swap = f.sw[k] != 0;
-          const double top = swap ? f.nxt[k] : cur, bot = swap ? cur : f.nxt[k];
-          z[(int64_t)(i0 + k) * ldz] = top;
-          cur = bot - f.l[k] * top;
-        }
-      }
+    double cur = z[0] * sc;
+    auto step_f = [&](const Fwd& f, int k, int row) {
+      const bool swap = f.sw[k] != 0;
+      const double nx = f.nxt[k] * sc;
+      const double top = swap ? nx : cur, bot = swap ? cur : nx;
+      z[(int64_t)row * ldz] = top;
+      cur = bot - f.l[k] * top;
     };
     if (n > 1) {
-      Fwd fa, fb;
+      const int nf = n - 1;
+      Fwd fa, fb2;
       load_f(fa, 0);
-      for (int i0 = 0; i0 < n - 1; i0 += 2 * CH) {
-        if (i0 + CH < n - 1) load_f(fb, i0 + CH);
-        run_f(fa, i0);
-        if (i0 + 2 * CH < n - 1) load_f(fa, i0 + 2 * CH);
-        if (i0 + CH < n - 1) run_f(fb, i0 + CH);
+      int i0 = 0;
+      for (; i0 + 2 * CH <= nf; i0 += 2 * CH) {
+        load_f(fb2, i0 + CH);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) step_f(fa, k, i0 + k);
+        load_f(fa, i0 + 2 * CH);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) step_f(fb2, k, i0 + CH + k);
+      }
+      // fewer than 2 CH rows left; fa holds the first CH of them
+      if (i0 + CH < nf) load_f(fb2, i0 + CH);
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        if (i0 + k < nf) step_f(fa, k, i0 + k);
+      if (i0 + CH < nf) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+          if (i0 + CH + k < nf) step_f(fb2, k, i0 + CH + k);
       }
     }
     // backward: U x = y
-    double x1 = cur * a.inv[(int64_t)(n - 1) * K + jj], x2 = 0.0;
+    double x1 = cur * a.inv[fi(n - 1)], x2 = 0.0;
     z[(int64_t)(n - 1) * ldz] = x1;
     nrm2 = x1 * x1;
-    auto run_b = [&](const Bwd& f, int i0) {
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        if (i0 - k >= 0) {
-          const double xi = (f.y[k] - f.u1[k] * x1 - f.u2[k] * x2) * f.r[k];
-          z[(int64_t)(i0 - k) * ldz] = xi;
-          nrm2 += xi * xi;
-          x2 = x1; x1 = xi;
-        }
-      }
+    auto step_b = [&](const Bwd& f, int k, int row) {
+      const double xi = (f.y[k] - f.u1[k] * x1 - f.u2[k] * x2) * f.r[k];
+      z[(int64_t)row * ldz] = xi;
+      nrm2 += xi * xi;
+      x2 = x1; x1 = xi;
     };
     if (n > 1) {
       Bwd ba, bb;
       load_b(ba, n - 2);
-      for (int i0 = n - 2; i0 >= 0; i0 -= 2 * CH) {
-        if (i0 - CH >= 0) load_b(bb, i0 - CH);
-        run_b(ba, i0);
-        if (i0 - 2 * CH >= 0) load_b(ba, i0 - 2 * CH);
-        if (i0 - CH >= 0) run_b(bb, i0 - CH);
+      int i0 = n - 2;
+      for (; i0 - 2 * CH + 1 >= 0; i0 -= 2 * CH) {
+        load_b(bb, i0 - CH);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) step_b(ba, k, i0 - k);
+        load_b(ba, i0 - 2 * CH);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) step_b(bb, k, i0 - CH - k);
+      }
+      if (i0 - CH >= 0) load_b(bb, i0 - CH);
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        if (i0 - k >= 0) step_b(ba, k, i0 - k);
+      if (i0 - CH >= 0) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+          if (i0 - CH - k >= 0) step_b(bb, k, i0 - CH - k);
       }
     }
-    if (it + 1 < a.iters) {  // keep the iterate in range: three unscaled solves can reach 1e48, more would overflow
-      const double s = 1.0 / sqrt(nrm2);
-#pragma unroll 8
-      for (int i = 0; i < n; ++i) z[i * ldz] *= s;
-    }
   }
+  // final normalisation: 32 independent rows in flight
   const double s = 1.0 / sqrt(nrm2);
-#pragma unroll 8
-  for (int i = 0; i < n; ++i) z[i * ldz] *= s;
+  {
+    int i = 0;
+    for (; i + 32 <= n; i += 32) {
+      double t[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) t[k] = z[(int64_t)(i + k) * ldz];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) z[(int64_t)(i + k) * ldz] = t[k] * s;
+    }
+    for (; i < n; ++i) z[(int64_t)i * ldz] *= s;
+  }
 }
 
 // Re-orthogonalisation inside every maximal run of kept eigenvalues whose neighbours are closer than
@@ -834,8 +868,9 @@ static EighWs eigh_ws(int n) {
   w.off_shift = take((size_t)n * 8);
   w.off_params = take(8 * 8);
   w.off_kept = take(64);
-  w.off_fac = take(4 * (size_t)n * n * 8);   // inv, du, du2, dl for up to n kept vectors
-  w.off_pv = take((size_t)n * n);
+  const size_t nk = (size_t)((n + 15) / 16) * 16 * (size_t)n;   // n vectors rounded up to whole waves of 16
+  w.off_fac = take(4 * nk * 8);   // inv, du, du2, dl for up to n kept vectors
+  w.off_pv = take(nk);
   w.bt_blocks = n > 2 ? (n - 2 + EIG_NB - 1) / EIG_NB : 0;
   w.bt_splits = (n + BT_RC - 1) / BT_RC;
   const size_t panel_bytes = bt_rows_before(n, w.bt_blocks) * EIG_NB * 8;   // ~ n^2 / 2 doubles
@@ -952,10 +987,11 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
   InvitArgs ia;
   ia.d = t.d; ia.e = t.e; ia.n = n; ia.shifts = shifts; ia.K = K; ia.params = params;
   double* fac = reinterpret_cast<double*>(b + w.off_fac);
+  const size_t fstride = (size_t)((K + INV_VPW - 1) / INV_VPW) * INV_VPW * (size_t)n;   // K rounded up to whole waves
   ia.inv = fac;
-  ia.du = fac + (size_t)n * K;
-  ia.du2 = fac + 2 * (size_t)n * K;
-  ia.dl = fac + 3 * (size_t)n * K;
+  ia.du = fac + fstride;
+  ia.du2 = fac + 2 * fstride;
+  ia.dl = fac + 3 * fstride;
   ia.pv = b + w.off_pv;
   ia.Z = V;
   ia.ldz = ldv;
