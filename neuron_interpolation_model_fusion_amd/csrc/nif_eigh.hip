@@ -68,7 +68,10 @@ struct TrdArgs {
 constexpr int TRD_EPT = (NIF_EIGH_MAX_N + TRD_T - 1) / TRD_T;  // vector elements a thread owns at most
 constexpr int TRD_W = TRD_T / 64;
 
-template <int CPW>
+// TWO: a second row group per workgroup is fetched before the vector phase as well (its own register set): for
+// trailing sizes where a workgroup owns about two groups, all of its share of the matrix is then in flight while the
+// latency-bound vector phase runs, instead of the second half being requested after it.
+template <int CPW, bool TWO>
 __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n = a.n, j = a.j, tid = threadIdx.x;
@@ -98,30 +101,44 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   bool live[TRD_ROWS];
   int rr[TRD_ROWS];
   double2 x[CPW][TRD_ROWS];
-  auto setup = [&](int grp) {
+  // the group after that (TWO only)
+  double* rowB[TRD_ROWS];
+  bool liveB[TRD_ROWS];
+  int rrB[TRD_ROWS];
+  double2 xB[TWO ? CPW : 1][TRD_ROWS];
+  auto setup = [&](int grp, double* (&row_)[TRD_ROWS], bool (&live_)[TRD_ROWS], int (&rr_)[TRD_ROWS]) {
 #pragma unroll
     for (int q = 0; q < TRD_ROWS; ++q) {
       int r = grp * TRD_ROWS + q;
-      live[q] = r >= j + 1 && r < n;
+      live_[q] = r >= j + 1 && r < n;
       r = r < j + 1 ? j + 1 : (r < n ? r : n - 1);  // clamped duplicates are loaded and discarded
-      rr[q] = r;
-      row[q] = a.A + (size_t)r * ld;
+      rr_[q] = r;
+      row_[q] = a.A + (size_t)r * ld;
     }
   };
-  auto fetch = [&]() {
+  auto fetch = [&](double* const (&row_)[TRD_ROWS], double2 (*x_)[TRD_ROWS]) {
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
       const int c = cw + 1024 * k;
       if (c < cend) {
 #pragma unroll
-        for (int q = 0; q < TRD_ROWS; ++q) x[k][q] = *reinterpret_cast<const double2*>(row[q] + c);
+        for (int q = 0; q < TRD_ROWS; ++q) x_[k][q] = *reinterpret_cast<const double2*>(row_[q] + c);
       }
     }
   };
   bool has = g * TRD_ROWS < n;
   if (has) {
-    setup(g);
-    fetch();
+    setup(g, row, live, rr);
+    fetch(row, x);
+  }
+  int gB = g + 8 * nsub;
+  bool hasB = false;
+  if constexpr (TWO) {
+    hasB = has && gB * TRD_ROWS < n;
+    if (hasB) {
+      setup(gB, rowB, liveB, rrB);
+      fetch(rowB, xB);
+    }
   }
 
   // ---- vector phase, identical in every workgroup
@@ -226,11 +243,30 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
     double* frow[TRD_ROWS];
 #pragma unroll
     for (int q = 0; q < TRD_ROWS; ++q) { frr[q] = rr[q]; flive[q] = live[q]; frow[q] = row[q]; }
-    g += 8 * nsub;
-    has = g * TRD_ROWS < n;
-    if (has) {
-      setup(g);
-      fetch();
+    if constexpr (TWO) {
+      // the group fetched earlier moves up, the one after it is requested
+      has = hasB;
+      if (has) {
+#pragma unroll
+        for (int q = 0; q < TRD_ROWS; ++q) { row[q] = rowB[q]; live[q] = liveB[q]; rr[q] = rrB[q]; }
+#pragma unroll
+        for (int k = 0; k < CPW; ++k)
+#pragma unroll
+          for (int q = 0; q < TRD_ROWS; ++q) x[k][q] = xB[TWO ? k : 0][q];
+        gB += 8 * nsub;
+        hasB = gB * TRD_ROWS < n;
+        if (hasB) {
+          setup(gB, rowB, liveB, rrB);
+          fetch(rowB, xB);
+        }
+      }
+    } else {
+      g += 8 * nsub;
+      has = g * TRD_ROWS < n;
+      if (has) {
+        setup(g, row, live, rr);
+        fetch(row, x);
+      }
     }
     double* part_ = rowpart + parity * (TRD_W * TRD_ROWS);
 #pragma unroll
@@ -930,13 +966,14 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
     if (lds > 160 * 1024) return NIF_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)trd_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)trd_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)trd_step_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)trd_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)trd_step_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const void* fns[] = {(const void*)trd_step_kernel<1, false>, (const void*)trd_step_kernel<2, false>,
+                           (const void*)trd_step_kernel<2, true>,  (const void*)trd_step_kernel<3, false>,
+                           (const void*)trd_step_kernel<3, true>,  (const void*)trd_step_kernel<4, false>,
+                           (const void*)trd_step_kernel<4, true>,  (const void*)trd_step_kernel<6, false>};
+      for (const void* fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
+    static const int trd_one = env_int("NIF_EIGH_TRD_ONE_GROUP");  // tuning aid: the single-prefetch kernels everywhere
     prof_begin(NIF_PROF_EIGH_TRD, st);
     double trd_bytes = 0.0;
     for (int j = 0; j + 2 < n; ++j) {
@@ -950,11 +987,16 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
       const int chunks = (cend - c0 + 127) / 128;
       const int cpw = (chunks + TRD_W - 1) / TRD_W;   // chunks of 128 columns a wave holds in flight per group
       const dim3 grid(8 * b8), block(TRD_T);
-      if (cpw <= 1) hipLaunchKernelGGL(trd_step_kernel<1>, grid, block, lds, st, t);
-      else if (cpw == 2) hipLaunchKernelGGL(trd_step_kernel<2>, grid, block, lds, st, t);
-      else if (cpw == 3) hipLaunchKernelGGL(trd_step_kernel<3>, grid, block, lds, st, t);
-      else if (cpw == 4) hipLaunchKernelGGL(trd_step_kernel<4>, grid, block, lds, st, t);
-      else hipLaunchKernelGGL(trd_step_kernel<6>, grid, block, lds, st, t);
+      // a second group in flight from the start wherever a workgroup owns more than one (register budget: CPW <= 4)
+      const bool two = groups > 8 * b8 && !trd_one;
+      if (cpw <= 1) hipLaunchKernelGGL((trd_step_kernel<1, false>), grid, block, lds, st, t);
+      else if (cpw == 2 && two) hipLaunchKernelGGL((trd_step_kernel<2, true>), grid, block, lds, st, t);
+      else if (cpw == 2) hipLaunchKernelGGL((trd_step_kernel<2, false>), grid, block, lds, st, t);
+      else if (cpw == 3 && two) hipLaunchKernelGGL((trd_step_kernel<3, true>), grid, block, lds, st, t);
+      else if (cpw == 3) hipLaunchKernelGGL((trd_step_kernel<3, false>), grid, block, lds, st, t);
+      else if (cpw == 4 && two) hipLaunchKernelGGL((trd_step_kernel<4, true>), grid, block, lds, st, t);
+      else if (cpw == 4) hipLaunchKernelGGL((trd_step_kernel<4, false>), grid, block, lds, st, t);
+      else hipLaunchKernelGGL((trd_step_kernel<6, false>), grid, block, lds, st, t);
     }
     hipLaunchKernelGGL(trd_finish_kernel, dim3(1), dim3(64), 0, st, t);
     prof_end(NIF_PROF_EIGH_TRD, st);
