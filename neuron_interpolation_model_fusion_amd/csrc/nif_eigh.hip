@@ -645,11 +645,42 @@ __global__ __launch_bounds__(ORT_T) void tri_ortho_kernel(const double* __restri
   for (int av = j0 + 1; av <= j1; ++av) {
     const int nbv = av - j0;
     for (int rep = 0; rep < 2; ++rep) {
+      if (nbv <= 16) {
+        // short runs (the usual case: two to a handful of close eigenvalues): all threads along the rows, four
+        // members at a time.  With the threads along the members, as below, a run of two kept four lanes busy, each
+        // walking n / 4 rows one dependent load after the other: 0.6 ms per inner product at n = 4609.
+        for (int b0 = 0; b0 < nbv; b0 += 4) {
+          double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+          for (int i = tid; i < n; i += ORT_T) {
+            const double* zr = Z + (int64_t)i * ldz;
+            const double za = zr[av];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a4[m] += (b0 + m < nbv ? zr[j0 + b0 + m] : 0.0) * za;
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) a4[m] = wave_sum_f64(a4[m]);
+          if (tx == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) part[ty][m] = a4[m];
+          }
+          __syncthreads();
+          if (tid < 4 && b0 + tid < nbv) {
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < ORT_T / 64; ++q) sum += part[q][tid];
+            coef[b0 + tid] = sum;
+          }
+          __syncthreads();
+        }
+      } else {
       for (int b0 = 0; b0 < nbv; b0 += 64) {
         const int bb = b0 + tx;
         double acc = 0.0;
-        if (bb < nbv)
+        if (bb < nbv) {
+#pragma unroll 8
           for (int i = ty; i < n; i += ORT_T / 64) acc += Z[(int64_t)i * ldz + j0 + bb] * Z[(int64_t)i * ldz + av];
+        }
         part[ty][tx] = acc;
         __syncthreads();
         if (ty == 0 && bb < nbv) {
@@ -659,6 +690,7 @@ __global__ __launch_bounds__(ORT_T) void tri_ortho_kernel(const double* __restri
           coef[bb] = sum;
         }
         __syncthreads();
+      }
       }
       for (int i = tid; i < n; i += ORT_T) {
         const double* zr = Z + (int64_t)i * ldz + j0;
