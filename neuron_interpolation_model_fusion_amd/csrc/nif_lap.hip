@@ -120,7 +120,10 @@ __global__ void lap_zero_init_kernel(int n, double* __restrict__ u, double* __re
 constexpr int LAP_MBOX_WORDS = 8;
 constexpr int LAP_MBOX_TOTAL = 2 * 16 * LAP_MBOX_WORDS;
 
-template <int CPT, bool SCIPY>
+// ONE: the block is a single wave (n <= 128): its winner is the block's winner, so the mailbox, the barrier and the
+// second reduction tree drop out.  A template parameter rather than a test of blockDim: with the test compiled into
+// the multi-wave kernel that kernel ran 7 % slower.
+template <int CPT, bool SCIPY, bool ONE = false>
 __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restrict__ C, int64_t ldc, int n,
                                                            double* __restrict__ u, double* __restrict__ vg,
                                                            int* __restrict__ col4row_g, int* __restrict__ row4col_g,
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
       const int poster = whi == NONE ? 0 : __ffsll(m) - 1;
       unsigned ghi, glo, gkey;
       int gcol, inext;
-      if (T == 64) {
+      if constexpr (ONE) {
         // one wave owns every column: its winner is the block's winner -- no mailbox, no barrier, no second tree
         ++step;
         if (whi == NONE) break;  // no candidate left
@@ -405,10 +408,10 @@ static LapWs lap_ws(int n) {
   return w;
 }
 
-template <int CPT, bool SCIPY>
+template <int CPT, bool SCIPY, bool ONE = false>
 static void launch_augment(int threads, size_t lds, hipStream_t st, const float* C, int64_t ldc, int n, double* u,
                            double* v, int* c4r, int* r4c, int* stats, int max_steps) {
-  auto kfn = lap_augment_kernel<CPT, SCIPY>;
+  auto kfn = lap_augment_kernel<CPT, SCIPY, ONE>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(1), dim3(threads), lds, st, C, ldc, n, u, v, c4r, r4c, stats, max_steps);
 }
@@ -537,16 +540,19 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
   if (threads > 1024) return NIF_ERR_UNSUPPORTED;
   const size_t lds = (size_t)((3 * n + 3) & ~3) * sizeof(int) + LAP_MBOX_TOTAL * sizeof(int);
   if (timed) prof_begin(NIF_PROF_LAP, st);
-#define NIF_LAP_GO(CPT)                                                                       \
+#define NIF_LAP_GO(CPT, ONE)                                                                       \
   do {                                                                                        \
-    if (scipy_order) launch_augment<CPT, true>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, 0); \
-    else launch_augment<CPT, false>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, max_steps);       \
+    if (scipy_order) launch_augment<CPT, true, ONE>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, 0); \
+    else launch_augment<CPT, false, ONE>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, max_steps);       \
   } while (0)
+  if (threads == 64 && cpt == 1) NIF_LAP_GO(1, true);
+  else if (threads == 64 && cpt == 2) NIF_LAP_GO(2, true);
+  else
   switch (cpt) {
-    case 1: NIF_LAP_GO(1); break;
-    case 2: NIF_LAP_GO(2); break;
-    case 4: NIF_LAP_GO(4); break;
-    default: NIF_LAP_GO(8); break;
+    case 1: NIF_LAP_GO(1, false); break;
+    case 2: NIF_LAP_GO(2, false); break;
+    case 4: NIF_LAP_GO(4, false); break;
+    default: NIF_LAP_GO(8, false); break;
   }
 #undef NIF_LAP_GO
   if (timed) prof_end(NIF_PROF_LAP, st);
