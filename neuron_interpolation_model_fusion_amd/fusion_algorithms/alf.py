@@ -26,7 +26,7 @@ from tqdm import trange
 from .. import ops
 from ..models.base_model import BaseModel
 from ..parallel import SampleSharding, allgather_rows, broadcast_parameters
-from ..utils.fusion_utils import get_num_levels, normalize_activations_per_sample, compute_neuron_importance_scores
+from ..utils.fusion_utils import get_num_levels, compute_neuron_importance_scores
 from ..utils.model_utils import (
     is_conv_activation, is_transformer_activation, reset_parameters, soft_reset_parameters, disable_dropout)
 
@@ -158,6 +158,32 @@ class ALFusion:
             return acts.permute(0, 3, 2, 1).reshape(-1, acts.shape[1])
         raise ValueError(f'Invalid shape for activations: {acts.shape}. Expected a 2D, 3D or 4D tensor.')
 
+    def _flatten_and_join(self, acts, normalize):
+        """``torch.cat([_flatten_acts(a) for a in acts], dim=1)`` and, with normalize, the same of the per-sample
+        normalised blocks (alf.py:181-189) -- each model's activations are transposed straight into their columns of
+        the joined matrix (one pass instead of a flattening copy plus a concatenating one), and the normalised
+        block is written into place by the division itself.  Same values as the separate steps."""
+        rows = acts[0].numel() // acts[0].shape[1]
+        N = sum(a.shape[1] for a in acts)
+        joined = torch.empty((rows, N), dtype=acts[0].dtype, device=acts[0].device)
+        normed = torch.empty_like(joined) if normalize else None
+        off = 0
+        for a in acts:
+            h = a.shape[1]
+            if a.dim() == 2:
+                joined[:, off:off + h].copy_(a)
+            elif a.dim() == 3:  # [B, hidden, seq] -> rows (b, s)
+                joined.view(a.shape[0], a.shape[2], N)[:, :, off:off + h].copy_(a.permute(0, 2, 1))
+            elif a.dim() == 4:  # [B, C, H, W] -> rows (b, w, h)
+                joined.view(a.shape[0], a.shape[3], a.shape[2], N)[..., off:off + h].copy_(a.permute(0, 3, 2, 1))
+            else:
+                raise ValueError(f'Invalid shape for activations: {a.shape}. Expected a 2D, 3D or 4D tensor.')
+            if normalize:
+                block = joined[:, off:off + h]
+                torch.div(block, torch.norm(block, dim=1, keepdim=True), out=normed[:, off:off + h])
+            off += h
+        return joined, (normed if normalize else joined)
+
     def _unflatten_target(self, T, target_width, height, width, seqlen):
         if height != 0 and width != 0:
             return T.reshape(-1, width, height, target_width).permute(0, 3, 2, 1)
@@ -243,14 +269,7 @@ class ALFusion:
             height, width = acts[0].shape[2], acts[0].shape[3]
         elif is_transformer_activation(acts[0]):
             seqlen = acts[0].shape[2]
-        acts = [self._flatten_acts(a) for a in acts]
-        if fusion_config.normalize_acts_for_kmeans:
-            kmeans_acts = torch.cat(tuple(normalize_activations_per_sample(a) for a in acts), dim=1).contiguous()
-        else:
-            kmeans_acts = None
-        acts = torch.cat(tuple(acts), dim=1).contiguous()
-        if kmeans_acts is None:
-            kmeans_acts = acts
+        acts, kmeans_acts = self._flatten_and_join(acts, fusion_config.normalize_acts_for_kmeans)
 
         ni_scores_of_level = [self.ni_scores[k][level_idx] for k in range(len(self.models))]
         sample_weight = torch.cat(ni_scores_of_level).to(dev)

@@ -194,3 +194,22 @@ def test_hook_capture_aliases_unless_the_model_has_an_inplace_module():
     pre0 = m.get_inputs_and_preactivations(0)[1]
     assert torch.allclose(pre0, ref) and bool((pre0 < 0).any())
     m.remove_hooks()
+
+
+def test_alf_flatten_and_join_equals_flatten_normalise_concatenate():
+    """ALFusion._flatten_and_join writes each model's block straight into the joined matrices; the values are those of
+    the reference's separate steps (alf.py:104-115, 181-189), bit for bit."""
+    import torch
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms.alf import ALFusion
+    from neuron_interpolation_model_fusion_amd.utils.fusion_utils import normalize_activations_per_sample
+    g = torch.Generator().manual_seed(3)
+    for shapes in ([(7, 5), (7, 9)], [(4, 6, 3), (4, 10, 3)], [(3, 4, 2, 5), (3, 8, 2, 5)]):
+        acts = [torch.randn(*sh, generator=g) for sh in shapes]
+        flat = [ALFusion._flatten_acts(None, a) for a in acts]
+        want = torch.cat(flat, dim=1)
+        want_n = torch.cat([normalize_activations_per_sample(f) for f in flat], dim=1)
+        joined, normed = ALFusion._flatten_and_join(None, acts, True)
+        assert joined.is_contiguous() and normed.is_contiguous()
+        assert torch.equal(joined, want) and torch.equal(normed, want_n)
+        joined2, same = ALFusion._flatten_and_join(None, acts, False)
+        assert same is joined2 and torch.equal(joined2, want)
