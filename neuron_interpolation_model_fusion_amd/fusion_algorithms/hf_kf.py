@@ -15,6 +15,7 @@ Same class, attributes and ``fuse`` signature.  What changed underneath, per lay
   matrix (ops.KMeans); the farthest-point initialisation reads one Gram row per step instead of
   recomputing a c x N x m cdist.
 """
+import os
 import time
 
 import numpy as np
@@ -27,6 +28,27 @@ from ..utils.fusion_utils import (
 from ..utils.model_utils import is_conv_weight
 
 COST_MATRIX_VECTORIZED_CHUNK_SIZE = 8  # kept for source compatibility (hf_kf.py:19); unused by the closed form
+
+
+def _levels_follow_layers(model, num_layers):
+    """True when the model can be walked level by level in place of layer by layer: it implements forward_level, has
+    as many levels as trainable layers, and level i holds trainable layer i and no other."""
+    from ..models.base_model import BaseModel
+    if type(model).forward_level is BaseModel.forward_level:
+        return False
+    try:
+        levels = model.get_ordered_trainable_named_levels
+        layers = model.get_ordered_trainable_named_layers
+    except Exception:  # a model without levels
+        return False
+    if len(levels) != num_layers or len(layers) != num_layers:
+        return False
+    trainable = {id(rep.layer) for rep in layers}
+    for level, rep in zip(levels, layers):
+        inside = {id(mod) for mod in level.network.modules()} & trainable
+        if inside != {id(rep.layer)}:
+            return False
+    return True
 
 
 class LSFusion:
@@ -243,9 +265,23 @@ class LSFusion:
         with twin_copy():
             fused_hat = self.models[0].copy_model().eval()
         self.last_layer_info = []
+        # The fused model's input of layer l changes with every layer fused before it; the reference re-runs the whole
+        # fused model for each layer (hf_kf.py:549: L^2 / 2 layer evaluations that matter, L^2 that run).  Where level l
+        # of the model is exactly trainable layer l plus parameter-free modules (VGG without batch norm, MLP), the
+        # levels are walked once instead: level l runs on the output of level l - 1 to capture the layer's input, and
+        # again after its weights are set -- the same modules on the same tensors, so the same numbers.
+        walk = os.environ.get('NIF_HF_FULL_FORWARD', '0') != '1' and _levels_follow_layers(fused_hat, num_layers)
+        cur = activation_dataset
+        if walk:
+            fused_hat.remove_hooks()
+            fused_hat.register_hooks()
         for layer_idx in range(num_layers):
             print(f'Fusing layer {layer_idx + 1}/{num_layers}')
-            initialize_activations(fused_hat, activation_dataset)  # the fused model's input changes every layer
+            if walk:
+                with torch.no_grad():
+                    fused_hat.forward_level(cur, layer_idx)  # the hook of layer l keeps its input
+            else:
+                initialize_activations(fused_hat, activation_dataset)  # the fused model's input changes every layer
             if fusion_method == 'hungarian':
                 new_W, new_b = self._fuse_layer_hungarian(layer_idx, fused_hat, norm_acts)
             else:
@@ -253,6 +289,9 @@ class LSFusion:
             fused_hat.set_weight_at_layer(layer_idx, new_W)
             if new_b is not None:
                 fused_hat.set_bias_at_layer(layer_idx, new_b)
+            if walk and layer_idx + 1 < num_layers:
+                with torch.no_grad():
+                    cur = fused_hat.forward_level(cur, layer_idx)
 
         for m in self.models:
             m.remove_hooks()

@@ -85,6 +85,25 @@ def test_hf_matches_reference_golden(dev, name):
     assert_state_close(fused, fused_state(z, 'hf'), rtol=1e-3)
 
 
+@pytest.mark.parametrize('name,method', [('mlp_small', 'hungarian'), ('vgg_tiny', 'hungarian'), ('vgg_tiny', 'k_means')])
+def test_hf_kf_level_walk_equals_full_forward_per_layer(dev, name, method, monkeypatch):
+    """LSFusion.fuse walks the fused model level by level where levels and layers coincide; the reference's order of
+    work (one full forward of the fused model per layer, hf_kf.py:549; NIF_HF_FULL_FORWARD=1) gives the same weights."""
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import LSFusion
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms.hf_kf import _levels_follow_layers
+    z = load_npz(name)
+    states = []
+    for full in ('0', '1'):
+        monkeypatch.setenv('NIF_HF_FULL_FORWARD', full)
+        models, X = build_models(name, z, dev)
+        assert _levels_follow_layers(models[0], len(models[0].get_ordered_trainable_named_layers))
+        np.random.seed(int(z['meta.seed'][0]))
+        fused = LSFusion(models[:2]).fuse(X, None, fusion_method=method, neuron_importance_method='uniform')
+        states.append({k: v.detach().cpu() for k, v in fused.state_dict().items()})
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+
+
 def test_hf_norm_acts_matches_reference_golden(dev):
     from neuron_interpolation_model_fusion_amd.fusion_algorithms import LSFusion
     z = load_npz('mlp_small')
