@@ -65,7 +65,7 @@ struct TrdArgs {
 // pass; a workgroup takes one group of TRD_ROWS rows at a time and its 8 waves split the COLUMNS of the group
 // (chunk t of 128 columns goes to wave t % 8), so all of a group's data is in flight at once -- CPW chunks per wave
 // -- and the first group's loads are issued before the vector phase starts.
-constexpr int TRD_EPT = (NIF_EIGH_MAX_N + TRD_T - 1) / TRD_T;  // vector elements a thread owns at most
+constexpr int TRD_EPT_MAX = (NIF_EIGH_MAX_N + TRD_T - 1) / TRD_T;  // vector elements a thread owns at most
 constexpr int TRD_W = TRD_T / 64;
 
 // TWO: a second row group per workgroup is fetched before the vector phase as well (its own register set): for
@@ -89,6 +89,9 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   const int cend = (n + 1) & ~1;             // one pad column when n is odd
   const bool pending = j > 0;
   const int lane = tid & 63, wv = tid >> 6;
+  // vector elements a thread owns: the rows j .. n-1 are at most 1024 CPW + 1 (the host picks CPW from the trailing
+  // width), so the loops below are CPW-sized instead of sized for the largest matrix
+  constexpr int TRD_EPT = 2 * CPW + 1 < TRD_EPT_MAX ? 2 * CPW + 1 : TRD_EPT_MAX;
 
   // ---- this workgroup's share of the trailing pass: row groups of TRD_ROWS consecutive rows (absolute numbering);
   // group g always goes to a workgroup with blockIdx % 8 == g % 8, i.e. (workgroups are dealt round-robin over the
