@@ -16,10 +16,27 @@ __device__ __forceinline__ double shfl_xor_f64(double x, int mask) {
   return __hiloint2double(hi, lo);
 }
 
+// Wave-wide f64 sum, the same value returned to every lane, through DPP row shifts / row broadcasts: a fixed tree
+// (sums of 2, 4, 8, 16 neighbours inside each row of 16 lanes, then rows 0+1 and 2+3, then the halves).  The xor
+// butterfly over __shfl_xor this replaces compiles to ds_bpermute on gfx950 -- twelve trips through the LDS
+// crossbar, ~0.3 us per sum, which was a sixth of a latency-bound tridiagonalisation step.  All 64 lanes must be
+// active at the call (a lane whose DPP source is inactive or outside its row adds 0).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum_f64(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += shfl_xor_f64(x, o);
-  return x;
+  x += dpp_f64<0x111, 0xf>(x);  // row_shr:1
+  x += dpp_f64<0x112, 0xf>(x);  // row_shr:2
+  x += dpp_f64<0x114, 0xf>(x);  // row_shr:4
+  x += dpp_f64<0x118, 0xf>(x);  // row_shr:8   -> lane 15 of each row of 16 holds the row's sum
+  x += dpp_f64<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+  x += dpp_f64<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63),
+                          __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
 
 // ---- wave-wide minimum through DPP row shifts / row broadcasts (no LDS crossbar traffic): the result is
