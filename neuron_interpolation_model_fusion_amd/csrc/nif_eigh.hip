@@ -34,11 +34,11 @@ constexpr int TRD_ROWS = 4;     // rows a wave carries through the trailing pass
 constexpr int EIG_NB = 64;      // reflectors per back-transformation block
 
 // deterministic block-wide sum (same value in every workgroup that runs the same code on the same data)
-template <int T>
+template <int T, bool FRESH = false>
 __device__ __forceinline__ double block_sum(double x, double* red /* T/64 + 1 doubles of LDS */) {
   x = wave_sum_f64(x);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __syncthreads();  // red may still be read from a previous call
+  if (!FRESH) __syncthreads();  // red may still be read from a previous call (FRESH: slots nobody has touched)
   if (lane == 0) red[wv] = x;
   __syncthreads();
   double s = 0.0;
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   double* sv1 = reinterpret_cast<double*>(smem_raw);
   double* sw = sv1 + ld;
   double* svj = sw + ld;
-  double* red = svj + ld;            // 8 reduction slots + 2 broadcast slots (+ 6 spare)
-  double* rowpart = red + 16;        // [2][TRD_W][TRD_ROWS] partial row sums, double-buffered by group parity
+  double* red = svj + ld;            // 8 reduction slots + 2 broadcast slots (+ 6 spare), 8 more for the second sum
+  double* rowpart = red + 32;        // [2][TRD_W][TRD_ROWS] partial row sums, double-buffered by group parity
   const double* vprev = a.vbuf + (size_t)((j + 1) & 1) * ld;  // parity of j - 1
   const double* yprev = a.ybuf + (size_t)((j + 1) & 1) * ld;
   double* vcur = a.vbuf + (size_t)(j & 1) * ld;
@@ -92,6 +92,26 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   // vector elements a thread owns: the rows j .. n-1 are at most 1024 CPW + 1 (the host picks CPW from the trailing
   // width), so the loops below are CPW-sized instead of sized for the largest matrix
   constexpr int TRD_EPT = 2 * CPW + 1 < TRD_EPT_MAX ? 2 * CPW + 1 : TRD_EPT_MAX;
+
+  // ---- loads of the vector phase first: they head the step's chain of dependent latencies (loads -> reduction ->
+  // reflector -> pass), the matrix rows requested right after them are not needed before the pass
+  double tau1 = 0.0, pj = 0.0, vjm = 0.0;
+  if (pending) {
+    tau1 = a.tau[j - 1];
+    pj = yprev[j];
+    vjm = vprev[j];  // = 1
+  }
+  double vv[TRD_EPT], pp[TRD_EPT], xx[TRD_EPT];
+  const double* arow = a.A + (size_t)j * ld;
+#pragma unroll
+  for (int it = 0; it < TRD_EPT; ++it) {
+    const int r = j + tid + it * TRD_T;
+    vv[it] = 0.0; pp[it] = 0.0; xx[it] = 0.0;
+    if (r < n) {
+      xx[it] = arow[r];
+      if (pending) { vv[it] = vprev[r]; pp[it] = yprev[r]; }
+    }
+  }
 
   // ---- this workgroup's share of the trailing pass: row groups of TRD_ROWS consecutive rows (absolute numbering);
   // group g always goes to a workgroup with blockIdx % 8 == g % 8, i.e. (workgroups are dealt round-robin over the
@@ -144,24 +164,7 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
     }
   }
 
-  // ---- vector phase, identical in every workgroup
-  double tau1 = 0.0, pj = 0.0, vjm = 0.0;
-  if (pending) {
-    tau1 = a.tau[j - 1];
-    pj = yprev[j];
-    vjm = vprev[j];  // = 1
-  }
-  double vv[TRD_EPT], pp[TRD_EPT], xx[TRD_EPT];
-  const double* arow = a.A + (size_t)j * ld;
-#pragma unroll
-  for (int it = 0; it < TRD_EPT; ++it) {
-    const int r = j + tid + it * TRD_T;
-    vv[it] = 0.0; pp[it] = 0.0; xx[it] = 0.0;
-    if (r < n) {
-      xx[it] = arow[r];
-      if (pending) { vv[it] = vprev[r]; pp[it] = yprev[r]; }
-    }
-  }
+  // ---- vector phase, identical in every workgroup (its loads were issued at the top)
   pj *= tau1;
   double part = 0.0;
 #pragma unroll
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
     part += pp[it] * vv[it];
   }
   // (a) w_{j-1} = p + alpha v with p = tau y, alpha = -tau/2 (p . v): rows j .. n-1 (v_{j-1}[j] = 1)
-  const double dot = pending ? block_sum<TRD_T>(part, red) : 0.0;
+  const double dot = pending ? block_sum<TRD_T, true>(part, red) : 0.0;
   const double alpha = -0.5 * tau1 * dot;
   const double wjm = pj + alpha * vjm;
   // (b) row j of the updated matrix (= its column j): x_c = A[j][c] - v[j] w[c] - w[j] v[c]
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
     }
   }
   if (tid == 0 && cend > n) { sv1[n] = 0.0; sw[n] = 0.0; svj[n] = 0.0; }
-  const double xnorm2 = block_sum<TRD_T>(part2, red);
+  const double xnorm2 = block_sum<TRD_T, true>(part2, red + 16);
   const double djj = red[8], alpha0 = red[9];
   double tau, beta, scale;
   if (xnorm2 == 0.0) {
@@ -997,7 +1000,7 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
   if (n <= 2) {
     hipLaunchKernelGGL(trd_small_kernel, dim3(1), dim3(64), 0, st, t);
   } else {
-    const size_t lds = (3 * (size_t)w.ld + 16 + 2 * TRD_W * TRD_ROWS) * sizeof(double);
+    const size_t lds = (3 * (size_t)w.ld + 32 + 2 * TRD_W * TRD_ROWS) * sizeof(double);
     if (lds > 160 * 1024) return NIF_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
