@@ -338,24 +338,27 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
         const int nnew = ctl[7];
         n_expand += nnew;
         int k = 0;
-        for (; k + 3 < nnew; k += 4) {
-          int ri[4];
-          double ru[4];
-          float cv[4][CPT];
+        constexpr int RB = CPT <= 2 ? 8 : 4;  // cost rows in flight
+        for (; k + RB - 1 < nnew; k += RB) {
+          int ri[RB];
+          double ru[RB];
+          float cv[RB][CPT];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) ri[q] = newrows[k + q];
+          for (int q = 0; q < RB; ++q) ri[q] = newrows[k + q];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < RB; ++q) {
             ru[q] = u[ri[q]];
             const float* __restrict__ crow = C + (int64_t)ri[q] * ldc;
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
+              // clamped address, no branch: a guarded load per row makes the compiler wait for every load in flight
+              // (s_waitcnt vmcnt(0)) before the next row's, which serialised the four rows of a batch
               const int j = tid + c * T;
-              cv[q][c] = j < n1 ? crow[j] : 0.f;
+              cv[q][c] = crow[j < n1 ? j : n1 - 1];
             }
           }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < RB; ++q) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
               const int j = tid + c * T;
