@@ -762,9 +762,11 @@ __global__ __launch_bounds__(256) void bt_gram_kernel(const double* __restrict__
     for (int k2 = 0; k2 < 4; ++k2) acc[i][k2] = 0.0;
   for (int rc = r0; rc < rend; rc += 32) {
     __syncthreads();
+#pragma unroll
     for (int q = tid; q < 32 * EIG_NB; q += 256) {
       const int rr = rc + q / EIG_NB;
-      sV[q / EIG_NB][q % EIG_NB] = rr < rend ? Vb[(size_t)rr * EIG_NB + q % EIG_NB] : 0.0;
+      const double x = Vb[(size_t)(rr < rend ? rr : rend - 1) * EIG_NB + q % EIG_NB];  // clamped, see bt_tile
+      sV[q / EIG_NB][q % EIG_NB] = rr < rend ? x : 0.0;
     }
     __syncthreads();
 #pragma unroll 8
@@ -840,13 +842,21 @@ __device__ __forceinline__ void bt_tile(const double* __restrict__ Vb, const dou
     for (int k2 = 0; k2 < 4; ++k2) acc[i][k2] = 0.0;
   for (int l0 = 0; l0 < nbk; l0 += LH) {
     __syncthreads();
+    // clamped addresses and a select, not guarded loads: a guard per element makes the compiler wait for each load
+    // before it issues the next (s_waitcnt vmcnt(0)), and a tile's sixteen loads per thread arrive one by one
+#pragma unroll
     for (int q = tid; q < 64 * LH; q += 256) {
       const int rr = q / LH, l = l0 + q % LH;
-      sV[rr][q % LH] = (r0 + rr < nr && l < nbk) ? Vb[(size_t)(r0 + rr) * EIG_NB + l] : 0.0;
+      const bool in = r0 + rr < nr && l < nbk;
+      const double x = Vb[(size_t)(r0 + rr < nr ? r0 + rr : nr - 1) * EIG_NB + (l < nbk ? l : nbk - 1)];
+      sV[rr][q % LH] = in ? x : 0.0;
     }
+#pragma unroll
     for (int q = tid; q < LH * 64; q += 256) {
       const int l = l0 + q / 64, cc = q % 64;
-      sY[q / 64][cc] = (cb + cc < K && l < nbk) ? Y[(size_t)l * ldy + cb + cc] : 0.0;
+      const bool in = cb + cc < K && l < nbk;
+      const double y = Y[(size_t)(l < nbk ? l : nbk - 1) * ldy + (cb + cc < K ? cb + cc : K - 1)];
+      sY[q / 64][cc] = in ? y : 0.0;
     }
     __syncthreads();
 #pragma unroll 8

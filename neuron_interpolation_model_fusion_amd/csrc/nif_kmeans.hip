@@ -638,20 +638,25 @@ __global__ void kmeans_hself_kernel(const GT* __restrict__ G, int64_t ldg, const
   double acc = 0.0;
   int u = seg[c];
   const int ue = seg[c + 1];
+  // f32 storage: the diagonal entry comes from its f64 array -- loaded once and SELECTED in, not fetched behind a
+  // branch (a guarded load per member makes the compiler wait for each load before the next is issued)
+  const double gii = sizeof(GT) == 4 ? gd[i] : 0.0;
   for (; u + 8 <= ue; u += 8) {  // eight independent loads in flight, added in member order
     double g[8], w[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int ip = order[u + q];
       w[q] = (double)s[ip];
-      g[q] = gram_at(G + (int64_t)ip * ldg, ip, i, gd);
+      const double gv = (double)G[(int64_t)ip * ldg + i];
+      g[q] = (sizeof(GT) == 4 && ip == i) ? gii : gv;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc += w[q] * g[q];
   }
   for (; u < ue; ++u) {
     const int ip = order[u];
-    acc += (double)s[ip] * gram_at(G + (int64_t)ip * ldg, ip, i, gd);
+    const double gv = (double)G[(int64_t)ip * ldg + i];
+    acc += (double)s[ip] * ((sizeof(GT) == 4 && ip == i) ? gii : gv);
   }
   hself[i] = acc / S[compact[c]];
 }
