@@ -157,22 +157,34 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const GT
     if (threadIdx.x == 0) picks[c] = idx;
     const GT* __restrict__ row = G + (int64_t)idx * ldg;
     const double gii = gram_at(row, idx, idx, gd);
+    // clamped addresses, eight loads in flight together (see the multi-workgroup kernel)
+    constexpr int LB = EPT < 8 ? EPT : 8;
     double bv = -INFINITY;
     int bj = INT_MAX;
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const int j = threadIdx.x + q * 1024;
-      if (j < N) {
-        double d2 = gii - 2.0 * gram_at(row, idx, j, gd) + nj[q];
-        if (!(d2 > 0.0)) d2 = 0.0;
-        const double d = sqrt(d2);
-        if (c == 0 || d < md[q]) {
-          md[q] = d;
-          lab[q] = c;
-        }
-        if (md[q] > bv) {  // j ascends within a thread: strict > keeps the lowest index
-          bv = md[q];
-          bj = j;
+    for (int q0 = 0; q0 < EPT; q0 += LB) {
+      double gv[LB];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const int j = threadIdx.x + (q0 + u) * 1024;
+        gv[u] = (double)row[j < N ? j : idx];
+      }
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const int q = q0 + u;
+        const int j = threadIdx.x + q * 1024;
+        if (j < N) {
+          double d2 = gii - 2.0 * ((sizeof(GT) == 4 && j == idx) ? gii : gv[u]) + nj[q];
+          if (!(d2 > 0.0)) d2 = 0.0;
+          const double d = sqrt(d2);
+          if (c == 0 || d < md[q]) {
+            md[q] = d;
+            lab[q] = c;
+          }
+          if (md[q] > bv) {  // j ascends within a thread: strict > keeps the lowest index
+            bv = md[q];
+            bj = j;
+          }
         }
       }
     }
@@ -239,13 +251,21 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const 
     if (b == 0 && tid == 0) picks[c] = idx;
     const GT* __restrict__ row = G + (int64_t)idx * ldg;
     const double gii = gram_at(row, idx, idx, gd);
+    // the row's entries through clamped addresses, all in flight together (a guarded load per element is waited for
+    // before the next is issued: EPT dependent round trips per pick instead of one)
+    double gv[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int j = j0 + tid + q * 1024;
+      gv[q] = (double)row[(tid + q * 1024 < span && j < N) ? j : idx];
+    }
     double bv = -INFINITY;
     int bj = INT_MAX;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
       const int j = j0 + tid + q * 1024;
       if (tid + q * 1024 < span && j < N) {
-        double d2 = gii - 2.0 * gram_at(row, idx, j, gd) + nj[q];
+        double d2 = gii - 2.0 * ((sizeof(GT) == 4 && j == idx) ? gii : gv[q]) + nj[q];
         if (!(d2 > 0.0)) d2 = 0.0;
         const double d = sqrt(d2);
         if (c == 0 || d < md[q]) {
