@@ -52,7 +52,8 @@ struct TrdArgs {
   int64_t ld;
   int n;
   int j;           // column being eliminated
-  double* vbuf;    // 2 x ld: reflector of step j at parity j & 1 (rows j+1 .. n-1, v[j+1] = 1)
+  double* vbuf;    // 3 x ld: reflector of step j in slot j % 3 (rows j+1 .. n-1, v[j+1] = 1)
+  double* wbuf;    // 2 x ld: w_{j-1} saved by a step that does not store the matrix (MODE 1), slot (j - 1) & 1
   double* ybuf;    // 2 x ld: y_j = (updated trailing matrix) v_j
   double* d;       // diagonal of T
   double* e;       // sub-diagonal of T
@@ -71,8 +72,17 @@ constexpr int TRD_W = TRD_T / 64;
 // TWO: a second row group per workgroup is fetched before the vector phase as well (its own register set): for
 // trailing sizes where a workgroup owns about two groups, all of its share of the matrix is then in flight while the
 // latency-bound vector phase runs, instead of the second half being requested after it.
-template <int CPW, bool TWO>
+//
+// MODE: the stores of the trailing pass -- and the write-back of 8 m^2 dirty bytes that the launch boundary waits
+// for -- are 18-40 % of a step above a trailing size of 1024.  So every other step leaves the matrix alone:
+//   MODE 1  one update pending (v_{j-1}, w_{j-1}): applied on the fly for y = A v_j, NOT stored; w_{j-1} is saved;
+//   MODE 2  two updates pending (j-2 from the saved vectors, j-1 as always): both applied, the result stored;
+//   MODE 0  the classic step (one pending, stored): first and last column, and wherever MODE 2 does not fit.
+// The older pair's vectors never enter LDS: a lane's columns are the same in every row group, so their entries sit
+// in registers for the whole step, and the four row entries of a group are fetched with the group.
+template <int CPW, bool TWO, int MODE>
 __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
+  constexpr bool KP2 = MODE == 2, STORE = MODE != 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n = a.n, j = a.j, tid = threadIdx.x;
   const int64_t ld = a.ld;
@@ -81,10 +91,13 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   double* svj = sw + ld;
   double* red = svj + ld;            // 8 reduction slots + 2 broadcast slots (+ 6 spare), 8 more for the second sum
   double* rowpart = red + 32;        // [2][TRD_W][TRD_ROWS] partial row sums, double-buffered by group parity
-  const double* vprev = a.vbuf + (size_t)((j + 1) & 1) * ld;  // parity of j - 1
+  const double* vprev = a.vbuf + (size_t)((j + 2) % 3) * ld;  // slot of j - 1
   const double* yprev = a.ybuf + (size_t)((j + 1) & 1) * ld;
-  double* vcur = a.vbuf + (size_t)(j & 1) * ld;
+  double* vcur = a.vbuf + (size_t)(j % 3) * ld;
   double* ycur = a.ybuf + (size_t)(j & 1) * ld;
+  const double* v2g = a.vbuf + (size_t)((j + 1) % 3) * ld;   // KP2: v_{j-2}
+  const double* w2g = a.wbuf + (size_t)(j & 1) * ld;         // KP2: w_{j-2}, saved by step j - 1
+  double* wsave = a.wbuf + (size_t)((j + 1) & 1) * ld;       // MODE 1: w_{j-1} goes here
   const int c0 = (j + 1) & ~1;               // first column of the 16-byte aligned trailing pass (j or j + 1)
   const int cend = (n + 1) & ~1;             // one pad column when n is odd
   const bool pending = j > 0;
@@ -102,14 +115,19 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
     vjm = vprev[j];  // = 1
   }
   double vv[TRD_EPT], pp[TRD_EPT], xx[TRD_EPT];
+  double v2r[KP2 ? TRD_EPT : 1], w2r[KP2 ? TRD_EPT : 1];
+  double v2j = 0.0, w2j = 0.0;
+  if constexpr (KP2) { v2j = v2g[j]; w2j = w2g[j]; }
   const double* arow = a.A + (size_t)j * ld;
 #pragma unroll
   for (int it = 0; it < TRD_EPT; ++it) {
     const int r = j + tid + it * TRD_T;
     vv[it] = 0.0; pp[it] = 0.0; xx[it] = 0.0;
+    if constexpr (KP2) { v2r[it] = 0.0; w2r[it] = 0.0; }
     if (r < n) {
       xx[it] = arow[r];
       if (pending) { vv[it] = vprev[r]; pp[it] = yprev[r]; }
+      if constexpr (KP2) { v2r[it] = v2g[r]; w2r[it] = w2g[r]; }
     }
   }
 
@@ -129,6 +147,24 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   bool liveB[TRD_ROWS];
   int rrB[TRD_ROWS];
   double2 xB[TWO ? CPW : 1][TRD_ROWS];
+  // KP2: the older pair at this lane's columns (fixed for the step) and at the rows of the group(s) in flight
+  double2 c2v[KP2 ? CPW : 1], c2w[KP2 ? CPW : 1];
+  double r2v[KP2 ? TRD_ROWS : 1], r2w[KP2 ? TRD_ROWS : 1], r2vB[KP2 && TWO ? TRD_ROWS : 1], r2wB[KP2 && TWO ? TRD_ROWS : 1];
+  if constexpr (KP2) {
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+      const int c = cw + 1024 * k;
+      const int cc = c < cend ? c : cend - 2;
+      c2v[k] = *reinterpret_cast<const double2*>(v2g + cc);
+      c2w[k] = *reinterpret_cast<const double2*>(w2g + cc);
+    }
+  }
+  auto fetch2 = [&](const int (&rr_)[TRD_ROWS], double* rv_, double* rw_) {
+    if constexpr (KP2) {
+#pragma unroll
+      for (int q = 0; q < TRD_ROWS; ++q) { rv_[q] = v2g[rr_[q]]; rw_[q] = w2g[rr_[q]]; }
+    }
+  };
   auto setup = [&](int grp, double* (&row_)[TRD_ROWS], bool (&live_)[TRD_ROWS], int (&rr_)[TRD_ROWS]) {
 #pragma unroll
     for (int q = 0; q < TRD_ROWS; ++q) {
@@ -153,6 +189,7 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
   if (has) {
     setup(g, row, live, rr);
     fetch(row, x);
+    fetch2(rr, r2v, r2w);
   }
   int gB = g + 8 * nsub;
   bool hasB = false;
@@ -161,6 +198,7 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
     if (hasB) {
       setup(gB, rowB, liveB, rrB);
       fetch(rowB, xB);
+      fetch2(rrB, r2vB, r2wB);
     }
   }
 
@@ -183,8 +221,11 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
     const int r = j + tid + it * TRD_T;
     if (r < n) {
       const double w = pp[it] + alpha * vv[it];
-      const double xr = xx[it] - vjm * w - wjm * vv[it];
+      double x0 = xx[it];
+      if constexpr (KP2) x0 -= v2j * w2r[it] + w2j * v2r[it];  // the older pending update, as a stored step applies it
+      const double xr = x0 - vjm * w - wjm * vv[it];
       xx[it] = xr;
+      if constexpr (MODE == 1) { if (blockIdx.x == 0) wsave[r] = w; }
       // column j is finished: it is masked out of the trailing pass (which starts at column j when j + 1 is odd)
       sv1[r] = r == j ? 0.0 : vv[it];
       sw[r] = r == j ? 0.0 : w;
@@ -236,10 +277,14 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
 #pragma unroll
         for (int q = 0; q < TRD_ROWS; ++q) {
           double2 y = x[k][q];
+          if constexpr (KP2) {
+            y.x -= r2v[q] * c2w[k].x + r2w[q] * c2v[k].x;
+            y.y -= r2v[q] * c2w[k].y + r2w[q] * c2v[k].y;
+          }
           y.x -= vr[q] * w2.x + wr[q] * v2.x;
           y.y -= vr[q] * w2.y + wr[q] * v2.y;
           acc[q] += y.x * u2.x + y.y * u2.y;
-          if (pending && live[q]) *reinterpret_cast<double2*>(row[q] + c) = y;
+          if (STORE && pending && live[q]) *reinterpret_cast<double2*>(row[q] + c) = y;
         }
       }
     }
@@ -255,6 +300,10 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
       if (has) {
 #pragma unroll
         for (int q = 0; q < TRD_ROWS; ++q) { row[q] = rowB[q]; live[q] = liveB[q]; rr[q] = rrB[q]; }
+        if constexpr (KP2 && TWO) {
+#pragma unroll
+          for (int q = 0; q < TRD_ROWS; ++q) { r2v[q] = r2vB[q]; r2w[q] = r2wB[q]; }
+        }
 #pragma unroll
         for (int k = 0; k < CPW; ++k)
 #pragma unroll
@@ -264,6 +313,7 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
         if (hasB) {
           setup(gB, rowB, liveB, rrB);
           fetch(rowB, xB);
+          fetch2(rrB, r2vB, r2wB);
         }
       }
     } else {
@@ -272,6 +322,7 @@ __global__ __launch_bounds__(TRD_T) void trd_step_kernel(TrdArgs a) {
       if (has) {
         setup(g, row, live, rr);
         fetch(row, x);
+        fetch2(rr, r2v, r2w);
       }
     }
     double* part_ = rowpart + parity * (TRD_W * TRD_ROWS);
@@ -303,7 +354,7 @@ __global__ void trd_finish_kernel(TrdArgs a) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int n = a.n, jl = n - 3;
   const int64_t ld = a.ld;
-  const double* v = a.vbuf + (size_t)(jl & 1) * ld;
+  const double* v = a.vbuf + (size_t)(jl % 3) * ld;
   const double* y = a.ybuf + (size_t)(jl & 1) * ld;
   const double tau1 = a.tau[jl];
   const int r0 = n - 2, r1 = n - 1;
@@ -929,7 +980,7 @@ __global__ void eigh_copy_lam_kernel(const double* __restrict__ lam, int n, int 
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct EighWs {
-  size_t off_A, off_vbuf, off_ybuf, off_d, off_e, off_tau, off_lam, off_shift, off_params, off_kept;
+  size_t off_A, off_vbuf, off_wbuf, off_ybuf, off_d, off_e, off_tau, off_lam, off_shift, off_params, off_kept;
   size_t off_fac, off_pv, off_Vall, off_VTall, off_Spart, off_Tall, off_M, off_xty, total;
   int bt_blocks, bt_splits;
   int64_t ld, ldz;
@@ -943,7 +994,8 @@ static EighWs eigh_ws(int n) {
   size_t o = 0;
   auto take = [&o](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
   w.off_A = take((size_t)n * w.ld * 8);
-  w.off_vbuf = take(2 * (size_t)w.ld * 8);
+  w.off_vbuf = take(3 * (size_t)w.ld * 8);
+  w.off_wbuf = take(2 * (size_t)w.ld * 8);
   w.off_ybuf = take(2 * (size_t)w.ld * 8);
   w.off_d = take((size_t)n * 8);
   w.off_e = take((size_t)n * 8);
@@ -996,6 +1048,7 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
   t.n = n;
   t.j = 0;
   t.vbuf = reinterpret_cast<double*>(b + w.off_vbuf);
+  t.wbuf = reinterpret_cast<double*>(b + w.off_wbuf);
   t.ybuf = reinterpret_cast<double*>(b + w.off_ybuf);
   t.d = reinterpret_cast<double*>(b + w.off_d);
   t.e = reinterpret_cast<double*>(b + w.off_e);
@@ -1012,18 +1065,32 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
   } else {
     const size_t lds = (3 * (size_t)w.ld + 32 + 2 * TRD_W * TRD_ROWS) * sizeof(double);
     if (lds > 160 * 1024) return NIF_ERR_UNSUPPORTED;
+    // kernel table: [mode][class][two]; classes 1, 2, 3, 4, 6 columns-chunks per wave
+    typedef void (*trd_fn)(TrdArgs);
+    static const trd_fn table[3][5][2] = {
+        {{trd_step_kernel<1, false, 0>, nullptr}, {trd_step_kernel<2, false, 0>, trd_step_kernel<2, true, 0>},
+         {trd_step_kernel<3, false, 0>, trd_step_kernel<3, true, 0>}, {trd_step_kernel<4, false, 0>, trd_step_kernel<4, true, 0>},
+         {trd_step_kernel<6, false, 0>, nullptr}},
+        {{trd_step_kernel<1, false, 1>, nullptr}, {trd_step_kernel<2, false, 1>, trd_step_kernel<2, true, 1>},
+         {trd_step_kernel<3, false, 1>, trd_step_kernel<3, true, 1>}, {trd_step_kernel<4, false, 1>, trd_step_kernel<4, true, 1>},
+         {nullptr, nullptr}},
+        {{trd_step_kernel<1, false, 2>, nullptr}, {trd_step_kernel<2, false, 2>, trd_step_kernel<2, true, 2>},
+         {trd_step_kernel<3, false, 2>, trd_step_kernel<3, true, 2>}, {trd_step_kernel<4, false, 2>, nullptr},
+         {nullptr, nullptr}}};
     static bool attr_set = false;
     if (!attr_set) {
-      const void* fns[] = {(const void*)trd_step_kernel<1, false>, (const void*)trd_step_kernel<2, false>,
-                           (const void*)trd_step_kernel<2, true>,  (const void*)trd_step_kernel<3, false>,
-                           (const void*)trd_step_kernel<3, true>,  (const void*)trd_step_kernel<4, false>,
-                           (const void*)trd_step_kernel<4, true>,  (const void*)trd_step_kernel<6, false>};
-      for (const void* fn : fns) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      for (int m = 0; m < 3; ++m)
+        for (int c = 0; c < 5; ++c)
+          for (int w2 = 0; w2 < 2; ++w2)
+            if (table[m][c][w2])
+              (void)hipFuncSetAttribute((const void*)table[m][c][w2], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
     static const int trd_one = env_int("NIF_EIGH_TRD_ONE_GROUP");  // tuning aid: the single-prefetch kernels everywhere
+    static const int trd_kp = env_int("NIF_EIGH_TRD_KP");          // tuning aid: 1 = every step stores (MODE 0 only)
     prof_begin(NIF_PROF_EIGH_TRD, st);
     double trd_bytes = 0.0;
+    int pend = 0;  // rank-2 updates not yet stored into the matrix when step j starts
     for (int j = 0; j + 2 < n; ++j) {
       t.j = j;
       trd_bytes += 16.0 * (double)(n - j - 1) * (double)(n - j - 1);
@@ -1035,16 +1102,20 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
       const int chunks = (cend - c0 + 127) / 128;
       const int cpw = (chunks + TRD_W - 1) / TRD_W;   // chunks of 128 columns a wave holds in flight per group
       const dim3 grid(8 * b8), block(TRD_T);
-      // a second group in flight from the start wherever a workgroup owns more than one (register budget: CPW <= 4)
-      const bool two = groups > 8 * b8 && !trd_one;
-      if (cpw <= 1) hipLaunchKernelGGL((trd_step_kernel<1, false>), grid, block, lds, st, t);
-      else if (cpw == 2 && two) hipLaunchKernelGGL((trd_step_kernel<2, true>), grid, block, lds, st, t);
-      else if (cpw == 2) hipLaunchKernelGGL((trd_step_kernel<2, false>), grid, block, lds, st, t);
-      else if (cpw == 3 && two) hipLaunchKernelGGL((trd_step_kernel<3, true>), grid, block, lds, st, t);
-      else if (cpw == 3) hipLaunchKernelGGL((trd_step_kernel<3, false>), grid, block, lds, st, t);
-      else if (cpw == 4 && two) hipLaunchKernelGGL((trd_step_kernel<4, true>), grid, block, lds, st, t);
-      else if (cpw == 4) hipLaunchKernelGGL((trd_step_kernel<4, false>), grid, block, lds, st, t);
-      else hipLaunchKernelGGL((trd_step_kernel<6, false>), grid, block, lds, st, t);
+      // every other step leaves the matrix unstored (MODE 1) and the next one applies both updates (MODE 2); the
+      // first step has nothing pending, the last one must store for trd_finish_kernel, above 4096 trailing
+      // columns the two-update kernel does not fit the register file, and up to 1024 the stores are too small a part
+      // of a step to pay for the second update (measured: 5.3 + 6.0 us per pair of steps against 2 x 5.3)
+      int mode;
+      if (pend == 2) mode = 2;
+      else if (pend == 1 && trd_kp != 1 && cpw >= 2 && cpw <= 4 && j + 3 < n) mode = 1;
+      else mode = 0;
+      pend = mode == 1 ? 2 : 1;
+      const int cls = cpw <= 1 ? 0 : (cpw == 2 ? 1 : (cpw == 3 ? 2 : (cpw == 4 ? 3 : 4)));
+      // a second group in flight from the start wherever a workgroup owns more than one and the registers allow it
+      int two = groups > 8 * b8 && !trd_one ? 1 : 0;
+      if (!table[mode][cls][two]) two = 0;
+      hipLaunchKernelGGL(table[mode][cls][two], grid, block, lds, st, t);
     }
     hipLaunchKernelGGL(trd_finish_kernel, dim3(1), dim3(64), 0, st, t);
     prof_end(NIF_PROF_EIGH_TRD, st);
