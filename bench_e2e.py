@@ -85,7 +85,7 @@ def run_c1(ops, device, steps, warmup):
                   'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,
                   'algorithmic_bytes': trd_bytes, 'kernel_ms_total': trd_ms, 'eigensolver_calls': calls,
                   'share_of_wall_clock': trd_ms * 1e-3 / sum(t_kf) if t_kf else None,
-                  'note': '16 (n-j-1)^2 bytes per column j; the pass is launch/latency-bound below n ~ 2500'})
+                  'note': '8 (n-j-1)^2 bytes read per column j plus 8 (n-j-1)^2 written by the steps that store the trailing matrix (every step up to a trailing size of 1024, every other step above); the pass is launch/latency-bound below n ~ 2500'})
 
 
 def run_c3(ops, device, steps, warmup, hidden=8192, batch=4096):

@@ -1093,7 +1093,6 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
     int pend = 0;  // rank-2 updates not yet stored into the matrix when step j starts
     for (int j = 0; j + 2 < n; ++j) {
       t.j = j;
-      trd_bytes += 16.0 * (double)(n - j - 1) * (double)(n - j - 1);
       const int groups = (n - (j + 1) / TRD_ROWS * TRD_ROWS + TRD_ROWS - 1) / TRD_ROWS;  // row groups still alive
       int b8 = (groups + 7) / 8;   // one group of rows per workgroup when they all fit
       if (b8 > 32) b8 = 32;
@@ -1111,6 +1110,8 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
       else if (pend == 1 && trd_kp != 1 && cpw >= 2 && cpw <= 4 && j + 3 < n) mode = 1;
       else mode = 0;
       pend = mode == 1 ? 2 : 1;
+      // algorithmic bytes of the step: the trailing matrix read once, and written once unless the step leaves it alone
+      trd_bytes += (mode == 1 || j == 0 ? 8.0 : 16.0) * (double)(n - j - 1) * (double)(n - j - 1);
       const int cls = cpw <= 1 ? 0 : (cpw == 2 ? 1 : (cpw == 3 ? 2 : (cpw == 4 ? 3 : 4)));
       // a second group in flight from the start wherever a workgroup owns more than one and the registers allow it
       int two = groups > 8 * b8 && !trd_one ? 1 : 0;
