@@ -769,16 +769,19 @@ __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* _
     }
     const acc_t* s = slab + (int64_t)si * n1p + sj;
     const int64_t stride = (int64_t)n0p * n1p;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four chains: fixed order, more loads in flight
+    // eight chains: fixed order, eight loads in flight per thread (the pass is a latency-bound stream over
+    // splits x n0p x n1p partials -- 113 MB at the C2 level -- and four in flight left it at half the bandwidth)
+    double c[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int k = 0;
-    for (; k + 3 < splits; k += 4) {
-      s0 += (double)s[(k + 0) * stride];
-      s1 += (double)s[(k + 1) * stride];
-      s2 += (double)s[(k + 2) * stride];
-      s3 += (double)s[(k + 3) * stride];
+    for (; k + 7 < splits; k += 8) {
+      acc_t t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = s[(k + q) * stride];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) c[q] += (double)t[q];
     }
-    for (; k < splits; ++k) s0 += (double)s[k * stride];
-    G[(int64_t)i * ldg + j] = (s0 + s1) + (s2 + s3);
+    for (; k < splits; ++k) c[0] += (double)s[k * stride];
+    G[(int64_t)i * ldg + j] = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
   } else {
     const bool is_a = i == n0;
     double* out = is_a ? na : nb;
@@ -786,8 +789,16 @@ __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* _
     if (out == nullptr || j >= n) return;
     const acc_t* ns = (is_a || symmetric) ? nsa : nsb;
     const int npad = (is_a || symmetric) ? n0p : n1p;
-    double sum = 0.0;
-    for (int k = 0; k < splits; ++k) sum += (double)ns[(int64_t)k * npad + j];
+    double sum = 0.0;  // one chain, in split order; the loads go out eight at a time
+    int k = 0;
+    for (; k + 7 < splits; k += 8) {
+      acc_t t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = ns[(int64_t)(k + q) * npad + j];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += (double)t[q];
+    }
+    for (; k < splits; ++k) sum += (double)ns[(int64_t)k * npad + j];
     out[j] = sum;
   }
 }
