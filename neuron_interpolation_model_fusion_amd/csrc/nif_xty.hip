@@ -761,13 +761,12 @@ __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* _
   const int i = blockIdx.y;
   if (i < n0) {
     if (j >= n1) return;
-    int si = i, sj = j;
-    if (symmetric && i > j) {  // lower triangle = mirror of the upper one, inside diagonal tiles too (the split-bf16
-                               // kernel's term order is not symmetric in i and j)
-      si = j;
-      sj = i;
-    }
-    const acc_t* s = slab + (int64_t)si * n1p + sj;
+    // symmetric: the lower triangle is the mirror of the upper one, inside diagonal tiles too (the split-bf16
+    // kernel's term order is not symmetric in i and j).  The thread of (i, j), i <= j, writes both entries: the mirror
+    // costs one strided store instead of `splits` strided loads (the lower triangle's threads used to read the slab
+    // down a column, one cache line per lane and split).
+    if (symmetric && i > j) return;
+    const acc_t* s = slab + (int64_t)i * n1p + j;
     const int64_t stride = (int64_t)n0p * n1p;
     // eight chains: fixed order, eight loads in flight per thread (the pass is a latency-bound stream over
     // splits x n0p x n1p partials -- 113 MB at the C2 level -- and four in flight left it at half the bandwidth)
@@ -781,7 +780,9 @@ __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* _
       for (int q = 0; q < 8; ++q) c[q] += (double)t[q];
     }
     for (; k < splits; ++k) c[0] += (double)s[k * stride];
-    G[(int64_t)i * ldg + j] = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    const double g = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    G[(int64_t)i * ldg + j] = g;
+    if (symmetric && i != j) G[(int64_t)j * ldg + i] = g;
   } else {
     const bool is_a = i == n0;
     double* out = is_a ? na : nb;
