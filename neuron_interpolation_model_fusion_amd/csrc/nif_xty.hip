@@ -756,9 +756,9 @@ template <typename acc_t>
 __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* __restrict__ nsa,
                                   const acc_t* __restrict__ nsb, int splits, int n0, int n1, int n0p, int n1p,
                                   int tm, int symmetric, double* __restrict__ G, int64_t ldg,
-                                  double* __restrict__ na, double* __restrict__ nb) {
+                                  double* __restrict__ na, double* __restrict__ nb, int ybase) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
+  const int i = blockIdx.y + ybase;  // ybase = n0: the two norm rows only
   if (i < n0) {
     if (j >= n1) return;
     // symmetric: the lower triangle is the mirror of the upper one, inside diagonal tiles too (the split-bf16
@@ -801,6 +801,53 @@ __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* _
     }
     for (; k < splits; ++k) sum += (double)ns[(int64_t)k * npad + j];
     out[j] = sum;
+  }
+}
+
+// Symmetric mode for large n: one workgroup per 64 x 64 tile of the upper triangle sums the tile into LDS and writes
+// it twice, as it stands and transposed, both in full rows -- the mirror is then a coalesced store (the general kernel's
+// mirror is one 8-byte store per cache line: 4.2 ms of a 5 ms reduction at n = 24 576).  Same chains per entry.
+template <typename acc_t>
+__global__ __launch_bounds__(256) void xty_reduce_sym_kernel(const acc_t* __restrict__ slab, int splits, int n, int np,
+                                                             double* __restrict__ G, int64_t ldg) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bi > bj) return;
+  __shared__ double tile[64][65];
+  const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+  const int64_t stride = (int64_t)np * np;
+  const int j = bj * 64 + c;
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int r = r0 + 4 * q, i = bi * 64 + r;
+    double g = 0.0;
+    if (i < n && j < n) {
+      const acc_t* s = slab + (int64_t)i * np + j;
+      double ch[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      int k = 0;
+      for (; k + 7 < splits; k += 8) {
+        acc_t t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = s[(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ch[u] += (double)t[u];
+      }
+      for (; k < splits; ++k) ch[0] += (double)s[k * stride];
+      g = ((ch[0] + ch[1]) + (ch[2] + ch[3])) + ((ch[4] + ch[5]) + (ch[6] + ch[7]));
+    }
+    tile[r][c] = g;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int r = r0 + 4 * q;
+    const int i = bi * 64 + r;
+    // the tile as it stands; inside a diagonal tile the lower entries mirror the upper ones
+    if (i < n && j < n) G[(int64_t)i * ldg + j] = (bi == bj && r > c) ? tile[c][r] : tile[r][c];
+    // and transposed: row bj * 64 + r of G, columns of block bi
+    if (bi != bj) {
+      const int mi = bj * 64 + r, mj = bi * 64 + c;
+      if (mi < n && mj < n) G[(int64_t)mi * ldg + mj] = tile[c][r];
+    }
   }
 }
 
@@ -1020,14 +1067,29 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
   const int sym = (flags & NIF_SYMMETRIC) ? 1 : 0;
   const int nmax = n0 > n1 ? n0 : n1;
   dim3 rg((nmax + 255) / 256, n0 + 2);
-  if (acc == NIF_F32) {
-    hipLaunchKernelGGL((xty_reduce_kernel<float>), rg, dim3(256), 0, st, (const float*)a.slab,
-                       (const float*)a.nslab_a, (const float*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm, sym,
-                       G, ldg, na, nb);
-  } else {
-    hipLaunchKernelGGL((xty_reduce_kernel<double>), rg, dim3(256), 0, st, (const double*)a.slab,
-                       (const double*)a.nslab_a, (const double*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm,
-                       sym, G, ldg, na, nb);
+  const int nt64 = (n0 + 63) / 64;
+  const bool sym_tiles = sym && nt64 >= 45;  // >= 1000 upper tiles: enough workgroups to fill the chip
+  int ybase = 0;
+  if (sym_tiles) {
+    if (acc == NIF_F32)
+      hipLaunchKernelGGL((xty_reduce_sym_kernel<float>), dim3(nt64, nt64), dim3(256), 0, st, (const float*)a.slab,
+                         pl.splits, n0, pl.n0p, G, ldg);
+    else
+      hipLaunchKernelGGL((xty_reduce_sym_kernel<double>), dim3(nt64, nt64), dim3(256), 0, st, (const double*)a.slab,
+                         pl.splits, n0, pl.n0p, G, ldg);
+    ybase = n0;  // the norm rows, if asked for, through the general kernel
+    rg = dim3((nmax + 255) / 256, 2);
+  }
+  if (!sym_tiles || na || nb) {
+    if (acc == NIF_F32) {
+      hipLaunchKernelGGL((xty_reduce_kernel<float>), rg, dim3(256), 0, st, (const float*)a.slab,
+                         (const float*)a.nslab_a, (const float*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm, sym,
+                         G, ldg, na, nb, ybase);
+    } else {
+      hipLaunchKernelGGL((xty_reduce_kernel<double>), rg, dim3(256), 0, st, (const double*)a.slab,
+                         (const double*)a.nslab_a, (const double*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm,
+                         sym, G, ldg, na, nb, ybase);
+    }
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
   return NIF_OK;

@@ -77,6 +77,24 @@ def test_xty_symmetric_relu_unaligned(ops, acc):
     assert ((G2.cpu() - Gr2).abs().max() / Gr2.abs().max()).item() < tol
 
 
+@pytest.mark.parametrize('acc', ['f32', 'f64'])
+@pytest.mark.parametrize('n,m', [(2881, 37), (3200, 20)])
+def test_xty_symmetric_large_n_goes_through_the_tile_reduction(ops, acc, n, m):
+    """From 45 tiles of 64 per side on, the symmetric reduction sums 64 x 64 tiles of the upper triangle and writes each
+    twice (as it stands and transposed): values against f64, exact symmetry, ragged last tile, norms on the side."""
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(m, n, generator=g)
+    G, na, _ = ops.xty(A.cuda(), None, acc=acc)
+    Gr = A.double().T @ A.double()
+    tol = 2e-6 if acc == 'f32' else 1e-12
+    Gc = G.cpu()
+    assert ((Gc - Gr).abs().max() / Gr.abs().max()).item() < tol
+    assert torch.equal(Gc, Gc.T)
+    assert torch.allclose(na.cpu(), torch.diagonal(Gr), rtol=tol * 10)
+    G2, _, _ = ops.xty(A.cuda(), None, acc=acc, norms=False)
+    assert torch.equal(G2.cpu(), Gc)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 def test_xty_transposed_operands(ops, dtype):
     g = torch.Generator().manual_seed(9)
