@@ -100,6 +100,12 @@ size_t nif_xty_workspace_bytes(int64_t m, int n0, int n1, int acc, int flags);
 int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, int n0, int n1,
             int in_dtype, int acc, int flags, double* G, int64_t ldg, double* na, double* nb,
             void* ws, size_t ws_bytes, void* stream);
+/* The symmetric Gram A^T A in the storage the k-means entry points stream (KF hf_kf.py:429-456, ALF alf.py:227-276):
+ * G (n x n, ldg) rounded once to f32, its diagonal in f64 (gdiag, n entries, required) -- the values nif_xty's f64 G
+ * rounds to, without the f64 matrix ever being written.  Workspace: nif_xty_workspace_bytes(m, n, n, acc,
+ * flags | NIF_SYMMETRIC).  flags: NIF_TRANS_A / NIF_RELU_A / NIF_XTY_SPLIT_BF16 as for nif_xty. */
+int nif_xty_sym_gf32(const void* A, int64_t lda, int64_t m, int n, int in_dtype, int acc, int flags, float* G,
+                     int64_t ldg, double* gdiag, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Cost-matrix epilogues: O(1) work per (i, j) on top of the Gram quantities.

@@ -42,6 +42,7 @@ SIGNATURES = {
     'nif_profile_work': (_i32, [_i32, _c.POINTER(_c.c_double)]),
     'nif_xty_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32]),
     'nif_xty': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    'nif_xty_sym_gf32': (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     'nif_cost_dist': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'nif_cost_hf': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'nif_lap_workspace_bytes': (_sz, [_i32]),

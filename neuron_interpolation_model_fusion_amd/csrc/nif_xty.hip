@@ -752,11 +752,13 @@ __global__ __launch_bounds__(NT, (FI == 3 ? 1 : 2)) void xty_bf16_kernel(const X
 
 // ---- slab + norm reduction, one launch --------------------------------------------------------------
 // blockIdx.y < n0: row i of G (threads along j); blockIdx.y == n0: na; == n0 + 1: nb.
-template <typename acc_t>
+// OT: storage type of G (double; float for the k-means storage, whose exact f64 diagonal goes to gdiag).
+template <typename acc_t, typename OT>
 __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* __restrict__ nsa,
                                   const acc_t* __restrict__ nsb, int splits, int n0, int n1, int n0p, int n1p,
-                                  int tm, int symmetric, double* __restrict__ G, int64_t ldg,
-                                  double* __restrict__ na, double* __restrict__ nb, int ybase) {
+                                  int tm, int symmetric, OT* __restrict__ G, int64_t ldg,
+                                  double* __restrict__ na, double* __restrict__ nb, int ybase,
+                                  double* __restrict__ gdiag) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y + ybase;  // ybase = n0: the two norm rows only
   if (i < n0) {
@@ -781,8 +783,9 @@ __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* _
     }
     for (; k < splits; ++k) c[0] += (double)s[k * stride];
     const double g = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
-    G[(int64_t)i * ldg + j] = g;
-    if (symmetric && i != j) G[(int64_t)j * ldg + i] = g;
+    G[(int64_t)i * ldg + j] = (OT)g;
+    if (symmetric && i != j) G[(int64_t)j * ldg + i] = (OT)g;
+    if (gdiag && i == j) gdiag[i] = g;
   } else {
     const bool is_a = i == n0;
     double* out = is_a ? na : nb;
@@ -807,9 +810,9 @@ __global__ void xty_reduce_kernel(const acc_t* __restrict__ slab, const acc_t* _
 // Symmetric mode for large n: one workgroup per 64 x 64 tile of the upper triangle sums the tile into LDS and writes
 // it twice, as it stands and transposed, both in full rows -- the mirror is then a coalesced store (the general kernel's
 // mirror is one 8-byte store per cache line: 4.2 ms of a 5 ms reduction at n = 24 576).  Same chains per entry.
-template <typename acc_t>
+template <typename acc_t, typename OT>
 __global__ __launch_bounds__(256) void xty_reduce_sym_kernel(const acc_t* __restrict__ slab, int splits, int n, int np,
-                                                             double* __restrict__ G, int64_t ldg) {
+                                                             OT* __restrict__ G, int64_t ldg, double* __restrict__ gdiag) {
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bi > bj) return;
   __shared__ double tile[64][65];
@@ -842,11 +845,14 @@ __global__ __launch_bounds__(256) void xty_reduce_sym_kernel(const acc_t* __rest
     const int r = r0 + 4 * q;
     const int i = bi * 64 + r;
     // the tile as it stands; inside a diagonal tile the lower entries mirror the upper ones
-    if (i < n && j < n) G[(int64_t)i * ldg + j] = (bi == bj && r > c) ? tile[c][r] : tile[r][c];
+    if (i < n && j < n) {
+      G[(int64_t)i * ldg + j] = (OT)((bi == bj && r > c) ? tile[c][r] : tile[r][c]);
+      if (gdiag && bi == bj && r == c) gdiag[i] = tile[r][c];
+    }
     // and transposed: row bj * 64 + r of G, columns of block bi
     if (bi != bj) {
       const int mi = bj * 64 + r, mj = bi * 64 + c;
-      if (mi < n && mj < n) G[(int64_t)mi * ldg + mj] = tile[c][r];
+      if (mi < n && mj < n) G[(int64_t)mi * ldg + mj] = (OT)tile[c][r];
     }
   }
 }
@@ -1003,11 +1009,11 @@ extern "C" size_t nif_xty_workspace_bytes(int64_t m, int n0, int n1, int acc, in
   return need;
 }
 
-extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, int n0, int n1, int in_dtype,
-                       int acc, int flags, double* G, int64_t ldg, double* na, double* nb, void* ws, size_t ws_bytes,
-                       void* stream) {
-  nif::Range nif_range_("nif_xty");
-  using namespace nif;
+namespace nif {
+template <typename OT>
+static int xty_impl(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, int n0, int n1, int in_dtype,
+                    int acc, int flags, OT* G, int64_t ldg, double* gdiag, double* na, double* nb, void* ws,
+                    size_t ws_bytes, void* stream) {
   // m == 0 (an empty shard): the operand pointers are never dereferenced and may be null
   if ((m > 0 && (!A || !B)) || !G || m < 0 || n0 <= 0 || n1 <= 0 || ldg < n1) return NIF_ERR_INVALID_ARG;
   if (in_dtype != NIF_F32 && in_dtype != NIF_F64) return NIF_ERR_INVALID_ARG;
@@ -1072,25 +1078,42 @@ extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, i
   int ybase = 0;
   if (sym_tiles) {
     if (acc == NIF_F32)
-      hipLaunchKernelGGL((xty_reduce_sym_kernel<float>), dim3(nt64, nt64), dim3(256), 0, st, (const float*)a.slab,
-                         pl.splits, n0, pl.n0p, G, ldg);
+      hipLaunchKernelGGL((xty_reduce_sym_kernel<float, OT>), dim3(nt64, nt64), dim3(256), 0, st, (const float*)a.slab,
+                         pl.splits, n0, pl.n0p, G, ldg, gdiag);
     else
-      hipLaunchKernelGGL((xty_reduce_sym_kernel<double>), dim3(nt64, nt64), dim3(256), 0, st, (const double*)a.slab,
-                         pl.splits, n0, pl.n0p, G, ldg);
+      hipLaunchKernelGGL((xty_reduce_sym_kernel<double, OT>), dim3(nt64, nt64), dim3(256), 0, st, (const double*)a.slab,
+                         pl.splits, n0, pl.n0p, G, ldg, gdiag);
     ybase = n0;  // the norm rows, if asked for, through the general kernel
     rg = dim3((nmax + 255) / 256, 2);
   }
   if (!sym_tiles || na || nb) {
     if (acc == NIF_F32) {
-      hipLaunchKernelGGL((xty_reduce_kernel<float>), rg, dim3(256), 0, st, (const float*)a.slab,
+      hipLaunchKernelGGL((xty_reduce_kernel<float, OT>), rg, dim3(256), 0, st, (const float*)a.slab,
                          (const float*)a.nslab_a, (const float*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm, sym,
-                         G, ldg, na, nb, ybase);
+                         G, ldg, na, nb, ybase, gdiag);
     } else {
-      hipLaunchKernelGGL((xty_reduce_kernel<double>), rg, dim3(256), 0, st, (const double*)a.slab,
+      hipLaunchKernelGGL((xty_reduce_kernel<double, OT>), rg, dim3(256), 0, st, (const double*)a.slab,
                          (const double*)a.nslab_a, (const double*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm,
-                         sym, G, ldg, na, nb, ybase);
+                         sym, G, ldg, na, nb, ybase, gdiag);
     }
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
   return NIF_OK;
+}
+}  // namespace nif
+
+extern "C" int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, int n0, int n1, int in_dtype,
+                       int acc, int flags, double* G, int64_t ldg, double* na, double* nb, void* ws, size_t ws_bytes,
+                       void* stream) {
+  nif::Range nif_range_("nif_xty");
+  return nif::xty_impl<double>(A, lda, B, ldb, m, n0, n1, in_dtype, acc, flags, G, ldg, nullptr, na, nb, ws, ws_bytes,
+                               stream);
+}
+
+extern "C" int nif_xty_sym_gf32(const void* A, int64_t lda, int64_t m, int n, int in_dtype, int acc, int flags, float* G,
+                                int64_t ldg, double* gdiag, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_xty_sym_gf32");
+  if (!gdiag) return NIF_ERR_INVALID_ARG;
+  return nif::xty_impl<float>(A, lda, A, lda, m, n, n, in_dtype, acc, flags | NIF_SYMMETRIC, G, ldg, gdiag, nullptr, nullptr,
+                              ws, ws_bytes, stream);
 }

@@ -276,8 +276,7 @@ class ALFusion:
         sw64 = sample_weight.double()
 
         # one symmetric Gram of the clustering vectors; everything below streams it
-        G, _, _ = ops.xty(kmeans_acts, None, acc='f32', norms=False, rows_sharded=True)
-        Gs, gdiag = ops.kmeans_gram_storage(G)
+        Gs, gdiag = ops.kmeans_gram(kmeans_acts, rows_sharded=True)
         km = ops.KMeans(Gs, gdiag, sample_weight, target_width, gdiag=gdiag)
 
         time_cc, iters = 0.0, 0

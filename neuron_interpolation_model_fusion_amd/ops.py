@@ -506,6 +506,32 @@ def kmeans_gram_storage(G):
     return G, gdiag
 
 
+def kmeans_gram(A, *, rows_sharded=False):
+    """``kmeans_gram_storage(xty(A, None, acc='f32', norms=False)[0])`` -- the symmetric Gram of the clustering vectors in
+    the storage the k-means kernels stream, (G f32, diagonal f64) -- without the f64 matrix in between: the split-K
+    reduction rounds each entry as it writes it and emits the diagonal unrounded (nif_xty_sym_gf32; same values bit
+    for bit, a third of the bytes and no conversion pass: at N = 24 576 the f64 matrix alone is 4.8 GB).  Inside a
+    SampleSharding context (the partial Grams are summed over the ranks in f64), for f64 inputs or with
+    NIF_KMEANS_G=f64 it takes the two steps."""
+    from .parallel import SampleSharding
+    A = _mat(A, 'A')
+    _need_gpu(A)
+    two_steps = (A.dtype != torch.float32 or os.environ.get('NIF_KMEANS_G', 'f32') == 'f64' or
+                 (rows_sharded and SampleSharding._active is not None))
+    if two_steps:
+        G, _, _ = xty(A, None, acc='f32', norms=False, rows_sharded=rows_sharded)
+        return kmeans_gram_storage(G)
+    m, n = A.shape
+    with torch.cuda.device(A.device):
+        G = torch.empty((n, n), dtype=torch.float32, device=A.device)
+        gdiag = torch.empty(n, dtype=torch.float64, device=A.device)
+        nbytes = lib.nif_xty_workspace_bytes(m, n, n, _lib.NIF_F32, _lib.NIF_SYMMETRIC)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=A.device)
+        check(lib.nif_xty_sym_gf32(_ptr(A), _ld(A), m, n, _DT[A.dtype], _lib.NIF_F32, 0, _ptr(G), n, _ptr(gdiag),
+                                   _ptr(ws), nbytes, _stream()), 'nif_xty_sym_gf32')
+    return G, gdiag
+
+
 class KMeans:
     """Device state of one Gram-form k-means problem (see nif_kmeans_* in include/nif.h).  G: N x N f64, or f32 with
     its unrounded diagonal in `gdiag` (taken from G itself when not given)."""

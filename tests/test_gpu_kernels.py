@@ -95,6 +95,24 @@ def test_xty_symmetric_large_n_goes_through_the_tile_reduction(ops, acc, n, m):
     assert torch.equal(G2.cpu(), Gc)
 
 
+@pytest.mark.parametrize('n,m', [(50, 33), (771, 100), (2950, 24)])
+def test_kmeans_gram_equals_the_rounded_f64_gram_bit_for_bit(ops, n, m):
+    """ops.kmeans_gram (nif_xty_sym_gf32: f32 storage + f64 diagonal straight out of the split-K reduction) against the
+    two steps it replaces, both reduction kernels (per-entry below 45 tiles of 64, tile-transposing above)."""
+    g = torch.Generator().manual_seed(n + m)
+    A = torch.randn(m, n, generator=g).cuda()
+    G, _, _ = ops.xty(A, None, acc='f32', norms=False)
+    want, want_d = ops.kmeans_gram_storage(G)
+    got, got_d = ops.kmeans_gram(A)
+    assert got.dtype == torch.float32 and got_d.dtype == torch.float64
+    assert torch.equal(got, want) and torch.equal(got_d, want_d)
+    # a column slice (row stride larger than the width)
+    B = torch.randn(m, n + 7, generator=g).cuda()
+    G2, _, _ = ops.xty(B[:, 3:n + 3], None, acc='f32', norms=False)
+    got2, got2_d = ops.kmeans_gram(B[:, 3:n + 3])
+    assert torch.equal(got2, G2.float()) and torch.equal(got2_d, torch.diagonal(G2))
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 def test_xty_transposed_operands(ops, dtype):
     g = torch.Generator().manual_seed(9)
