@@ -194,7 +194,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    # NIF_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, packed all-reduce per level on the front stream,
+    # barrier, max over ranks) with a single rank too -- the way to run the RCCL path on a one-GPU box
+    force_dist = world == 1 and os.environ.get('NIF_BENCH_FORCE_DIST') == '1'
+    if force_dist:
+        for key, val in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29533'), ('RANK', '0'), ('WORLD_SIZE', '1')):
+            os.environ.setdefault(key, val)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
@@ -356,7 +362,7 @@ def main():
                             f'tokens), n={n}, uniform marginals; ground-metric Gram + exact assignment + refit',
                 'rows_per_gpu': hi - lo,
                 'parallelism': f'rows sharded over {world} GPU(s), one f64 all-reduce of [G|na|nb] per level'
-                               if world > 1 else 'single GPU',
+                               if dist is not None else 'single GPU',
                 'lap_instance': 'planted (noisy column permutation: the dual initialisation matches nearly every row)',
                 'planted_permutation_recovered': recovered,
                 'hard_instance': hard,
