@@ -781,10 +781,36 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += (double)ssorted[t + u] * g[u];
     }
-    for (; t < e; ++t) {
-      const int i = order[t];
-      const double gv = (double)col[(int64_t)i * ldg];
-      acc += (double)ssorted[t] * ((sizeof(GT) == 4 && i == jc) ? gjj : gv);
+    // the remainder: exactly the rows that exist, in flight together, summed in the same sequence
+    auto tail = [&](auto width) {
+      constexpr int R = decltype(width)::value;
+      int idx[R];
+      float wv[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        idx[u] = order[t + u];
+        wv[u] = ssorted[t + u];
+      }
+      GT gr[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) gr[u] = col[(int64_t)idx[u] * ldg];
+      // the values are pinned here: left alone, the compiler sinks the last load into the branch of the lanes whose own
+      // row it is not and waits for it there, after the others -- a second round trip
+#pragma unroll
+      for (int u = 0; u < R; ++u) asm volatile("" : "+v"(gr[u]));
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+        acc += (double)wv[u] * ((sizeof(GT) == 4 && idx[u] == jc) ? gjj : (double)gr[u]);
+    };
+    switch (e - t) {
+      case 1: tail(std::integral_constant<int, 1>()); break;
+      case 2: tail(std::integral_constant<int, 2>()); break;
+      case 3: tail(std::integral_constant<int, 3>()); break;
+      case 4: tail(std::integral_constant<int, 4>()); break;
+      case 5: tail(std::integral_constant<int, 5>()); break;
+      case 6: tail(std::integral_constant<int, 6>()); break;
+      case 7: tail(std::integral_constant<int, 7>()); break;
+      default: break;
     }
     const double d2 = cn[cc] - 2.0 * (acc / S[cc]) + nj;
     if (d2 < best) {
