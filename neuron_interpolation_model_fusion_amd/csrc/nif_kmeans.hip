@@ -770,7 +770,7 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
     const int b = seg[c], e = seg[c + 1];
     double acc = 0.0;
     int t = b;
-    for (; t + 8 <= e; t += 8) {
+    for (; t + 16 <= e; t += 8) {  // chunks of eight while sixteen or more rows are left ...
       double g[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -802,14 +802,12 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
       for (int u = 0; u < R; ++u)
         acc += (double)wv[u] * ((sizeof(GT) == 4 && idx[u] == jc) ? gjj : (double)gr[u]);
     };
-    switch (e - t) {
-      case 1: tail(std::integral_constant<int, 1>()); break;
-      case 2: tail(std::integral_constant<int, 2>()); break;
-      case 3: tail(std::integral_constant<int, 3>()); break;
-      case 4: tail(std::integral_constant<int, 4>()); break;
-      case 5: tail(std::integral_constant<int, 5>()); break;
-      case 6: tail(std::integral_constant<int, 6>()); break;
-      case 7: tail(std::integral_constant<int, 7>()); break;
+    switch (e - t) {  // ... then all the rest at once (at most fifteen rows: one round trip for nearly every cluster)
+#define NIF_KM_TAIL(R) case R: tail(std::integral_constant<int, R>()); break;
+      NIF_KM_TAIL(1) NIF_KM_TAIL(2) NIF_KM_TAIL(3) NIF_KM_TAIL(4) NIF_KM_TAIL(5)
+      NIF_KM_TAIL(6) NIF_KM_TAIL(7) NIF_KM_TAIL(8) NIF_KM_TAIL(9) NIF_KM_TAIL(10)
+      NIF_KM_TAIL(11) NIF_KM_TAIL(12) NIF_KM_TAIL(13) NIF_KM_TAIL(14) NIF_KM_TAIL(15)
+#undef NIF_KM_TAIL
       default: break;
     }
     const double d2 = cn[cc] - 2.0 * (acc / S[cc]) + nj;
