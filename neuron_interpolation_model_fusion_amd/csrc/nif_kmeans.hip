@@ -169,6 +169,9 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const GT
         const int j = threadIdx.x + (q0 + u) * 1024;
         gv[u] = (double)row[j < N ? j : idx];
       }
+      // pinned: the compiler otherwise sinks each load into the `j < N` block that uses it and waits for it there
+#pragma unroll
+      for (int u = 0; u < LB; ++u) asm volatile("" : "+v"(gv[u]));
 #pragma unroll
       for (int u = 0; u < LB; ++u) {
         const int q = q0 + u;
@@ -259,6 +262,9 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const 
       const int j = j0 + tid + q * 1024;
       gv[q] = (double)row[(tid + q * 1024 < span && j < N) ? j : idx];
     }
+    // pinned: the compiler otherwise sinks the loads into the guarded blocks that use them, one round trip each
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) asm volatile("" : "+v"(gv[q]));
     double bv = -INFINITY;
     int bj = INT_MAX;
 #pragma unroll
