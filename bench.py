@@ -112,7 +112,8 @@ class LevelPipeline:
         self.ops, self.lv, self.dist = ops, lv, dist
         self.s_front, self.s_back = torch.cuda.Stream(), torch.cuda.Stream()
 
-    def run(self, steps):
+    def run(self, steps, marks=None):
+        """marks (a list): gets one timing event per level, recorded on the back stream when the level is complete."""
         cur = torch.cuda.current_stream()
         self.s_front.wait_stream(cur)
         self.s_back.wait_stream(cur)
@@ -132,6 +133,10 @@ class LevelPipeline:
                 with torch.cuda.stream(self.s_back):
                     self.s_back.wait_event(pending[1])
                     out = level_back(self.ops, self.lv, pending[0])
+                    if marks is not None:
+                        ev_done = torch.cuda.Event(enable_timing=True)
+                        ev_done.record(self.s_back)
+                        marks.append(ev_done)
             pending = nxt
         cur.wait_stream(self.s_front)
         cur.wait_stream(self.s_back)
@@ -175,6 +180,7 @@ def main():
     ap.add_argument('--rows', type=int, default=M_ROWS)
     ap.add_argument('--width', type=int, default=WIDTH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end fusion wall-clocks (config.e2e, N = 1)')
     ap.add_argument('--gram', choices=['f32', 'split-bf16'], default='f32',
                     help='matrix path of the Gram kernel: exact f32 MFMA (default, the parity path) or six bf16 MFMAs '
                          'on the exact three-way bf16 split of every operand (f32-level accuracy, different last bits)')
@@ -240,26 +246,60 @@ def main():
     overlap = not args.no_overlap and (world == 1 or args.overlap_multi or args.backend == 'nccl')
     pipe = LevelPipeline(ops, lv, dist) if overlap else None
 
-    def run_levels(count):
+    def run_levels(count, marks=None):
         if count <= 0:
             return None
         if pipe is not None:
-            return pipe.run(count)
+            return pipe.run(count, marks)
         for _ in range(count):
             res = level_step(ops, lv, dist)
+            if marks is not None:
+                ev_done = torch.cuda.Event(enable_timing=True)
+                ev_done.record()
+                marks.append(ev_done)
         return res
 
+    # Pre-heat: the same loop for a fixed wall time before anything is counted, whatever --warmup says.  A cold GPU
+    # (idle clocks, code objects not yet resident, allocator empty) gave 0.815 ms per Gram launch over 5 + 20 levels
+    # where 2000 levels average 0.728 ms; `warmup` stays the flag's count of untimed levels and runs after this.
+    preheat_s = max(0.0, float(os.environ.get('NIF_BENCH_PREHEAT_MS', '1500')) * 1e-3)
+    t_pre = time.perf_counter()
+    preheat_levels = 0
+    while True:
+        # every rank must run the same number of collectives: rank 0's clock decides
+        go = torch.tensor([1.0 if time.perf_counter() - t_pre < preheat_s else 0.0], device=device)
+        if dist is not None:
+            dist.broadcast(go, src=0)
+        if float(go.item()) == 0.0:
+            break
+        run_levels(50)
+        preheat_levels += 50
+        torch.cuda.synchronize()
+    preheat_ms = (time.perf_counter() - t_pre) * 1e3
     out = run_levels(args.warmup)
     sync()
     ops.profile_collect(ops.PROF_XTY)
     if not args.no_kernel_timing:
         ops.profile_enable(True, slots=[ops.PROF_XTY])  # spans of the dominant kernel only: each costs dispatch gaps
+    marks = []
+    ev_start = torch.cuda.Event(enable_timing=True)
+    ev_start.record()
     t0 = time.perf_counter()
-    out = run_levels(args.steps)
+    out = run_levels(args.steps, marks)
     sync()
     elapsed = time.perf_counter() - t0
     ops.profile_enable(False)
-    kernel_ms, launches = ops.profile_collect(ops.PROF_XTY)
+    spans = ops.profile_collect_spans(ops.PROF_XTY, cap=max(args.steps, 1) + 16)
+    kernel_ms, launches = sum(spans), len(spans)
+    # per-level completion times on the GPU's clock: level i took marks[i] - marks[i - 1] (the first one includes the
+    # pipeline fill)
+    step_ms = [a.elapsed_time(b) for a, b in zip([ev_start] + marks[:-1], marks)]
+
+    def stats(xs):
+        if not xs:
+            return None
+        ys = sorted(xs)
+        return {'min': ys[0], 'median': ys[len(ys) // 2], 'max': ys[-1], 'mean': sum(ys) / len(ys), 'n': len(ys)}
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,6 +360,12 @@ def main():
               'reg': sinkhorn_level.reg, 'plan_argmax_equals_planted_permutation': plan_argmax_ok,
               'note': 'additional approximate mode (nif_sinkhorn_f32), not the reference solver'}
 
+    # Fourth (N = 1): the wall-clock half of BASELINE.json's metric -- whole fusions of configs 1, 3 and 4
+    e2e = None
+    if world == 1 and not args.no_e2e:
+        import bench_e2e
+        e2e = bench_e2e.summary(ops, device)
+
     # sanity: the planted permutation is recovered (N = 1: exactly this rank's data; N > 1: summed Gram)
     col = out[0].long()
     recovered = bool((col == lv['perm']).all())  # model-k neuron i is target neuron perm[i] plus noise
@@ -367,7 +413,11 @@ def main():
                 'planted_permutation_recovered': recovered,
                 'hard_instance': hard,
                 'sinkhorn_mode': sk,
+                'e2e': e2e,
                 'overlap': 'two-stream software pipeline over levels' if overlap else 'serial',
+                'preheat_ms': preheat_ms,
+                'preheat_levels': preheat_levels,
+                'step_ms': stats(step_ms),
             },
             'roofline': {
                 'kernel': 'nif::xty_kernel<float, MmaF32> (v_mfma_f32_32x32x2_f32)' if args.gram == 'f32'
@@ -382,6 +432,7 @@ def main():
                                 f'this command, profiles/{TRAFFIC_FILE})',
                 'algorithmic_bytes_per_launch': 2.0 * (hi - lo) * n * 4,
                 'avg_kernel_ms': avg_ms,
+                'kernel_ms': stats(spans),
                 'launches': launches,
                 'algorithmic_flops_per_launch': flops,
             },

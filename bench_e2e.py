@@ -224,3 +224,26 @@ def run(workload, ops, device, steps, warmup):
         'vs_baseline': None, 'dtype': 'f32 inputs; f64 normal equations / duals', 'data': 'synthetic',
         'config': dict(workload=r['workload'], **r['extra']), 'roofline': r['roofline'],
     }
+
+
+def summary(ops, device, steps=2):
+    """End-to-end wall-clock of the BASELINE.json configurations that fit one GPU, for bench.py's default line
+    (config.e2e): seconds per whole fusion, mean of `steps` runs after one warm-up run each."""
+    out = {}
+    r = run('c1', ops, device, steps, 1)
+    out['c1_kf_s'] = r['value']
+    out['c1_hf_s'] = r['config']['hf2_seconds']
+    out['c1_trd_hbm_frac'] = r['roofline']['frac']
+    torch.cuda.empty_cache()
+    r = run('c3', ops, device, steps, 1)
+    out['c3_s'] = r['value']
+    out['c3_planted_permutation_recovered'] = r['config']['planted_permutation_recovered']
+    torch.cuda.empty_cache()
+    r = run('c4', ops, device, steps, 1)
+    out['c4_s'] = r['value']
+    torch.cuda.empty_cache()
+    out['what'] = ('c1: LSFusion.fuse of random-init VGG11s, 400 samples (KF 4 models / HF 2 models); c3: GitRebasin.fuse '
+                   'of two 784-8192-10 MLPs, 4096 samples, planted permutation; c4: ALF clustering + targets on the 7 hidden '
+                   'levels of two ViTs, 5000 samples (SGD fit not timed); `python bench.py --workload c1|c3|c4` prints '
+                   'each with its roofline')
+    return out

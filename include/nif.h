@@ -63,13 +63,17 @@ int nif_device_count(void);
  * summed milliseconds and launch count of a slot and clears it.  No reference counterpart
  * (the reference only prints time.time() deltas, hf_kf.py:211-214,245-247).
  * ------------------------------------------------------------------------- */
-#define NIF_PROFILE_SLOTS 4
+#define NIF_PROFILE_SLOTS 5
 #define NIF_PROF_XTY 0
 #define NIF_PROF_LAP 1
 #define NIF_PROF_KMEANS 2
 #define NIF_PROF_EIGH_TRD 3 /* all tridiagonalisation passes of one nif_eigh_kept_f64 call (one span per call) */
+#define NIF_PROF_SINKHORN 4 /* all iterations of one nif_sinkhorn_f32 call (one span per call) */
 void nif_profile_enable(int on); /* bit s set: record spans of slot s; negative: every slot; 0: off */
 int nif_profile_collect(int slot, double* total_ms, int64_t* launches);
+/* The same spans one by one, in record order: ms_out[0 .. min(cap, *launches)) (HOST floats); consumes them like
+ * nif_profile_collect.  For per-launch minimum / median / maximum of a kernel (bench.py). */
+int nif_profile_collect_spans(int slot, float* ms_out, int64_t cap, int64_t* launches);
 /* Algorithmic work the entry points booked for the recorded spans of a slot since the last call (then cleared).
  * NIF_PROF_EIGH_TRD: bytes of the fused update + matrix-vector passes, 16 (n - j - 1)^2 per column j (each element of
  * the trailing matrix read once and written once).  The other slots book nothing: their callers know the shapes. */
@@ -231,6 +235,13 @@ int nif_kmeans_farthest_init_batch_gf32(const float* G, int64_t ldg, const doubl
                                         int k, const int32_t* firsts, int tries, int32_t* picks, int32_t* assign,
                                         double* mind, void* stream);
 
+/* Above N = 4096 the initialisation runs on up to 16 co-operating workgroups per try that exchange one (maximum,
+ * index) pair per pick.  If their exchange times out (the workgroups of a try were not resident together: another
+ * stream or process held the compute units) the try is done again by one workgroup inside the same call, so the
+ * outputs are always complete; this diagnostic returns how many tries took that slow path on the current device
+ * since the process started (*count_host: HOST uint32; blocks on `stream`).  No counterpart in the reference. */
+int nif_kmeans_farthest_init_redo_count(uint32_t* count_host, void* stream);
+
 /* ALF initial assignment, alf.py:221-229: centroids are neurons c0 .. c0+k-1. */
 int nif_kmeans_assign_to_neurons(const double* G, int64_t ldg, const double* nn, int N, int k, int c0,
                                  int32_t* assign, void* stream);
@@ -360,6 +371,12 @@ int nif_im2row_f32(const float* x, int64_t batch, int C, int H, int W, int kh, i
 size_t nif_eigh_kept_workspace_bytes(int n);
 int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cutoff_rel, double* lam, double* V, int64_t ldv,
                       int32_t* kept_host, void* ws, size_t ws_bytes, void* stream);
+
+/* Diagnostic for the parity tests (no counterpart in the reference): launches of each tridiagonalisation step kernel
+ * since the process started, counts30[(mode * 5 + cls) * 2 + two] with mode 0 = update + store, 1 = update left
+ * pending, 2 = two pending updates applied; cls 0..4 = 1, 2, 3, 4, 6 column chunks per wave; two = second row group
+ * prefetched.  HOST array of 30 uint64. */
+int nif_eigh_trd_launch_counts(uint64_t* counts30);
 
 /* ---- least-squares refit W = pinv(X) A: hf_kf.py:213 (`torch.linalg.pinv(X)`), :233-234 and :377,:397
  * (`pinv @ acts`) -------------------------------------------------------------------------------------------

@@ -39,6 +39,7 @@ SIGNATURES = {
     'nif_device_count': (_i32, []),
     'nif_profile_enable': (None, [_i32]),
     'nif_profile_collect': (_i32, [_i32, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
+    'nif_profile_collect_spans': (_i32, [_i32, _c.POINTER(_c.c_float), _c.c_int64, _c.POINTER(_c.c_int64)]),
     'nif_profile_work': (_i32, [_i32, _c.POINTER(_c.c_double)]),
     'nif_xty_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32]),
     'nif_xty': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -85,6 +86,8 @@ SIGNATURES = {
     'nif_lsq_solve_workspace_bytes': (_sz, [_i32, _i32]),
     'nif_lsq_solve_f64': (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _c.c_double, _vp, _i64, _c.POINTER(_c.c_int32), _vp, _sz,
                                  _vp]),
+    'nif_kmeans_farthest_init_redo_count': (_i32, [_c.POINTER(_c.c_uint32), _vp]),
+    'nif_eigh_trd_launch_counts': (_i32, [_c.POINTER(_c.c_uint64)]),
     'nif_eigh_kept_workspace_bytes': (_sz, [_i32]),
     'nif_eigh_kept_f64': (_i32, [_vp, _i64, _i32, _c.c_double, _vp, _vp, _i64, _c.POINTER(_c.c_int32), _vp, _sz, _vp]),
 }

@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace nif {
 
 __device__ __forceinline__ double shfl_xor_f64(double x, int mask) {
@@ -105,6 +107,24 @@ static inline int env_int(const char* name) {
   const char* e = getenv(name);
   return e ? atoi(e) : 0;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: a process that uses the library on
+// several GPUs has to raise it on each.  A call site keeps one of these (function-local static) and runs its
+// attribute calls through it: once per device ordinal (devices beyond 63: every call), under a lock, so that a second
+// host thread cannot launch before the first has finished setting the attribute.
+struct PerDeviceOnce {
+  std::mutex mu;
+  unsigned long long done = 0;
+  template <typename F>
+  void run(F&& f) {
+    int dev = -1;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    std::lock_guard<std::mutex> lk(mu);
+    if (known && (done >> dev & 1ull)) return;
+    f();
+    if (known) done |= 1ull << dev;
+  }
+};
 
 // hipGetLastError() is per-thread state shared with every other HIP user in the process (torch's
 // event polling leaves hipErrorNotReady behind), so entry points clear it first and read it after

@@ -83,8 +83,8 @@ extern "C" void nif_profile_enable(int on) {
   nif::g_enabled = on < 0 ? ~0u : (unsigned)on;  // bit s = slot s; negative = every slot
 }
 
-extern "C" int nif_profile_collect(int slot, double* total_ms, int64_t* launches) {
-  if (!total_ms || !launches || slot < 0 || slot >= NIF_PROFILE_SLOTS) return NIF_ERR_INVALID_ARG;
+// durations of a slot's finished spans in record order (the spans are consumed): the first `cap` go to ms_out
+static int collect_spans(int slot, double* total_ms, int64_t* launches, float* ms_out, int64_t cap) {
   std::lock_guard<std::mutex> lk(nif::g_mu);
   double tot = 0.0;
   int64_t cnt = 0;
@@ -96,6 +96,7 @@ extern "C" int nif_profile_collect(int slot, double* total_ms, int64_t* launches
     }
     float ms = 0.f;
     if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      if (ms_out && cnt < cap) ms_out[cnt] = ms;
       tot += ms;
       ++cnt;
     }
@@ -106,6 +107,17 @@ extern "C" int nif_profile_collect(int slot, double* total_ms, int64_t* launches
   *total_ms = tot;
   *launches = cnt;
   return NIF_OK;
+}
+
+extern "C" int nif_profile_collect(int slot, double* total_ms, int64_t* launches) {
+  if (!total_ms || !launches || slot < 0 || slot >= NIF_PROFILE_SLOTS) return NIF_ERR_INVALID_ARG;
+  return collect_spans(slot, total_ms, launches, nullptr, 0);
+}
+
+extern "C" int nif_profile_collect_spans(int slot, float* ms_out, int64_t cap, int64_t* launches) {
+  if (!launches || slot < 0 || slot >= NIF_PROFILE_SLOTS || cap < 0 || (cap > 0 && !ms_out)) return NIF_ERR_INVALID_ARG;
+  double tot = 0.0;
+  return collect_spans(slot, &tot, launches, ms_out, cap);
 }
 
 // ---- roctx ranges ---------------------------------------------------------------------------------------------

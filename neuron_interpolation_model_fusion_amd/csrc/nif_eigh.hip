@@ -1023,7 +1023,19 @@ static EighWs eigh_ws(int n) {
   return w;
 }
 
+// launches of every trd_step_kernel<CPW, TWO, MODE> since the process started: [mode][class][two]
+static unsigned long long g_trd_launches[3][5][2];
+
 }  // namespace nif
+
+extern "C" int nif_eigh_trd_launch_counts(uint64_t* counts30) {
+  if (!counts30) return NIF_ERR_INVALID_ARG;
+  for (int m = 0; m < 3; ++m)
+    for (int c = 0; c < 5; ++c)
+      for (int w = 0; w < 2; ++w)
+        counts30[(m * 5 + c) * 2 + w] = __atomic_load_n(&nif::g_trd_launches[m][c][w], __ATOMIC_RELAXED);
+  return NIF_OK;
+}
 
 extern "C" size_t nif_eigh_kept_workspace_bytes(int n) {
   if (n <= 0 || n > NIF_EIGH_MAX_N) return 0;
@@ -1071,23 +1083,23 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
         {{trd_step_kernel<1, false, 0>, nullptr}, {trd_step_kernel<2, false, 0>, trd_step_kernel<2, true, 0>},
          {trd_step_kernel<3, false, 0>, trd_step_kernel<3, true, 0>}, {trd_step_kernel<4, false, 0>, trd_step_kernel<4, true, 0>},
          {trd_step_kernel<6, false, 0>, nullptr}},
-        {{trd_step_kernel<1, false, 1>, nullptr}, {trd_step_kernel<2, false, 1>, trd_step_kernel<2, true, 1>},
+        {{nullptr, nullptr}, {trd_step_kernel<2, false, 1>, trd_step_kernel<2, true, 1>},
          {trd_step_kernel<3, false, 1>, trd_step_kernel<3, true, 1>}, {trd_step_kernel<4, false, 1>, trd_step_kernel<4, true, 1>},
          {nullptr, nullptr}},
-        {{trd_step_kernel<1, false, 2>, nullptr}, {trd_step_kernel<2, false, 2>, trd_step_kernel<2, true, 2>},
+        {{nullptr, nullptr}, {trd_step_kernel<2, false, 2>, trd_step_kernel<2, true, 2>},
          {trd_step_kernel<3, false, 2>, trd_step_kernel<3, true, 2>}, {trd_step_kernel<4, false, 2>, nullptr},
          {nullptr, nullptr}}};
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;  // the attribute is per device: a second GPU of the process needs it too
+    attr_once.run([&] {
       for (int m = 0; m < 3; ++m)
         for (int c = 0; c < 5; ++c)
           for (int w2 = 0; w2 < 2; ++w2)
             if (table[m][c][w2])
               (void)hipFuncSetAttribute((const void*)table[m][c][w2], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    static const int trd_one = env_int("NIF_EIGH_TRD_ONE_GROUP");  // tuning aid: the single-prefetch kernels everywhere
-    static const int trd_kp = env_int("NIF_EIGH_TRD_KP");          // tuning aid: 1 = every step stores (MODE 0 only)
+    });
+    // tuning aids, read per call (the parity tests switch them inside one process to reach every kernel of the table)
+    const int trd_one = env_int("NIF_EIGH_TRD_ONE_GROUP");  // the single-prefetch kernels everywhere
+    const int trd_kp = env_int("NIF_EIGH_TRD_KP");          // 1 = every step stores (MODE 0 only)
     prof_begin(NIF_PROF_EIGH_TRD, st);
     double trd_bytes = 0.0;
     int pend = 0;  // rank-2 updates not yet stored into the matrix when step j starts
@@ -1116,7 +1128,11 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
       // a second group in flight from the start wherever a workgroup owns more than one and the registers allow it
       int two = groups > 8 * b8 && !trd_one ? 1 : 0;
       if (!table[mode][cls][two]) two = 0;
+      // (a MODE 1 step runs at an odd column j and its MODE 2 partner at j + 1, which has the same first trailing
+      // column pair c0 and hence the same class: classes without a MODE 1 kernel need no MODE 2 kernel either)
+      if (!table[mode][cls][two]) return NIF_ERR_UNSUPPORTED;
       hipLaunchKernelGGL(table[mode][cls][two], grid, block, lds, st, t);
+      __atomic_fetch_add(&g_trd_launches[mode][cls][two], 1ull, __ATOMIC_RELAXED);
     }
     hipLaunchKernelGGL(trd_finish_kernel, dim3(1), dim3(64), 0, st, t);
     prof_end(NIF_PROF_EIGH_TRD, st);
@@ -1128,11 +1144,10 @@ extern "C" int nif_eigh_kept_f64(const double* G, int64_t ldg, int n, double cut
   hipLaunchKernelGGL(tri_bounds_kernel, dim3(1), dim3(256), 0, st, t.d, t.e, n, params);
   {
     const size_t lds = 2 * (size_t)n * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    attr_once.run([&] {
       (void)hipFuncSetAttribute((const void*)tri_eigenvalues_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(tri_eigenvalues_kernel, dim3((n + BIS_T / BIS_P - 1) / (BIS_T / BIS_P)), dim3(BIS_T), lds, st, t.d, t.e, n,
                        params, lam_all);
   }

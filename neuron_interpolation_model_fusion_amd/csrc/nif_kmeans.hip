@@ -91,12 +91,21 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_kernel(const GT* __
                                                                     const double* __restrict__ nn, int N, int k,
                                                                     FiFirsts fb, int* __restrict__ picks,
                                                                     int* __restrict__ assign,
-                                                                    double* __restrict__ mind) {
+                                                                    double* __restrict__ mind,
+                                                                    unsigned* __restrict__ redo_count) {
   __shared__ double sv[16];
   __shared__ int sj[16];
   picks += (size_t)blockIdx.y * k;
   assign += (size_t)blockIdx.y * N;
   mind += (size_t)blockIdx.y * N;
+  if (redo_count) {
+    // second launch behind the multi-workgroup kernel: only a try whose exchange timed out (last pick left at -1) is
+    // done again, from scratch, by this one workgroup -- same arithmetic, same picks, no exchange to wait for
+    const bool failed = picks[k - 1] < 0;
+    __syncthreads();  // every thread has read the flag before thread 0 overwrites the picks
+    if (!failed) return;
+    if (threadIdx.x == 0) atomicAdd(redo_count, 1u);
+  }
   int idx = fb.first[blockIdx.y];
   for (int c = 0; c < k; ++c) {
     if (threadIdx.x == 0) picks[c] = idx;
@@ -212,12 +221,19 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_reg_kernel(const GT
 // with agent-scope loads until every tag shows the current pick, and each workgroup reduces them the same way
 // (larger value, lower index on ties), so all continue with the same pick.  Slots are double-buffered by pick parity:
 // a workgroup can be at most one pick ahead of the slowest reader.  The mailbox is zeroed by the launch function
-// before every call; spins are bounded (a timeout marks the remaining picks -1 and every workgroup leaves).
+// before every call; spins are bounded.  The exchange needs the workgroups of a try co-resident, which nothing
+// guarantees (another stream or process may hold the CUs): a timeout marks the remaining picks -1, every workgroup of
+// the try leaves, and the launch function ALWAYS queues the one-workgroup kernel behind this one in its
+// "only where picks[k - 1] < 0" mode, which redoes such a try from scratch -- the caller never sees a partial
+// initialisation, and nif_kmeans_farthest_init_redo_count says how often that happened.  `inject` (tests only)
+// makes the last workgroup declare a timeout at pick 2.
 constexpr int FI_MAX_WG = 16;
 constexpr int FI_GRANULES = 2 * FI_MAX_WG * 3;          // per call region: [parity][workgroup][hi, lo, idx]
 constexpr int FI_REGION_WORDS = FI_GRANULES + 32;       // + timeout word, padded: 128 x 8 bytes = 1 KiB
-constexpr int FI_REGIONS = 64;                          // calls in flight at once (each takes the next region)
+constexpr int FI_SLOTS = 8;                             // calls in flight at once per device (one slot each) ...
+constexpr int FI_REGIONS = FI_SLOTS * 16;               // ... of FI_MAX_TRIES regions, one per try
 static __device__ __align__(256) unsigned long long fi_mailbox[FI_REGIONS * FI_REGION_WORDS];
+static __device__ unsigned fi_redo_count;               // tries redone by the one-workgroup kernel on this device
 
 template <int EPT, typename GT>
 __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const GT* __restrict__ G, int64_t ldg, const double* __restrict__ gd,
@@ -225,7 +241,7 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const 
                                                                           FiFirsts fb, int span, int* __restrict__ picks,
                                                                           int* __restrict__ assign,
                                                                           double* __restrict__ mind,
-                                                                          unsigned long long* mbox) {
+                                                                          unsigned long long* mbox, int inject) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   __shared__ double sv[16];
   __shared__ int sj[16];
@@ -307,8 +323,8 @@ __global__ __launch_bounds__(1024) void kmeans_farthest_init_multi_kernel(const 
         } else {
           ok = true;
         }
-        if (__all(ok)) break;
-        if (spins > (1u << 22) ||
+        if (__all(ok) && !(inject && c == 2 && b == B - 1)) break;
+        if (spins > (1u << 22) || (inject && c == 2 && b == B - 1) ||
             (spins % 64 == 63 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
           failed = true;
           break;
@@ -1301,6 +1317,54 @@ extern "C" size_t nif_kmeans_workspace_bytes(int N, int k) {
 
 namespace nif {
 
+// mailbox slots of the multi-workgroup farthest-point initialisation, per device (shared by the f32 and f64 storage
+// instantiations of the launch function, hence not inside the template)
+struct FiDevice {
+  unsigned long long* base = nullptr;
+  unsigned* redo = nullptr;
+  hipEvent_t done[FI_SLOTS] = {};
+  bool used[FI_SLOTS] = {};
+  unsigned next = 0;
+};
+static std::mutex fi_mu;
+static FiDevice fi_devs[64];
+
+static int fi_device(int* dev_out) {  // fi_mu held
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NIF_ERR_NO_DEVICE;
+  FiDevice& fd = fi_devs[dev];
+  if (!fd.base) {
+    void *p = nullptr, *q = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(fi_mailbox)) != hipSuccess || !p) return NIF_ERR_NO_DEVICE;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(fi_redo_count)) != hipSuccess || !q) return NIF_ERR_NO_DEVICE;
+    fd.base = reinterpret_cast<unsigned long long*>(p);
+    fd.redo = reinterpret_cast<unsigned*>(q);
+  }
+  *dev_out = dev;
+  return NIF_OK;
+}
+
+static int fi_acquire(int* dev_out, int* slot_out) {  // fi_mu held
+  const int rc = fi_device(dev_out);
+  if (rc != NIF_OK) return rc;
+  FiDevice& fd = fi_devs[*dev_out];
+  int slot = -1;
+  for (int i = 0; i < FI_SLOTS && slot < 0; ++i) {
+    const int c = (int)((fd.next + (unsigned)i) % FI_SLOTS);
+    if (!fd.used[c] || hipEventQuery(fd.done[c]) == hipSuccess) slot = c;
+  }
+  if (slot < 0) {
+    slot = (int)(fd.next % FI_SLOTS);
+    if (hipEventSynchronize(fd.done[slot]) != hipSuccess) return NIF_ERR_LAUNCH;
+  }
+  (void)hipGetLastError();  // hipEventQuery leaves hipErrorNotReady behind
+  fd.next = (unsigned)slot + 1u;
+  if (!fd.done[slot] && hipEventCreateWithFlags(&fd.done[slot], hipEventDisableTiming) != hipSuccess)
+    return NIF_ERR_LAUNCH;
+  *slot_out = slot;
+  return NIF_OK;
+}
+
 template <typename GT>
 static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const double* nn, int N, int k,
                             const int32_t* firsts, int tries, int32_t* picks, int32_t* assign, double* mind,
@@ -1317,39 +1381,37 @@ static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const do
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int fi_single = env_int("NIF_KMEANS_INIT_SINGLE_WG");  // tuning aid: keep the one-workgroup kernel
   if (N > 4096 && N <= FI_MAX_WG * 4096 && !fi_single) {
-    // several workgroups per try, one mailbox exchange per pick (see kmeans_farthest_init_multi_kernel)
-    static std::mutex mu;
-    static unsigned long long* base[64];
-    static unsigned seq = 0;
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NIF_ERR_NO_DEVICE;
-    unsigned long long* region;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      if (!base[dev]) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(fi_mailbox)) != hipSuccess || !p) return NIF_ERR_NO_DEVICE;
-        base[dev] = reinterpret_cast<unsigned long long*>(p);
-      }
-      unsigned r0 = seq % FI_REGIONS;  // `tries` consecutive regions, never wrapping
-      if (r0 + (unsigned)tries > (unsigned)FI_REGIONS) r0 = 0;
-      seq = r0 + (unsigned)tries;
-      region = base[dev] + (size_t)r0 * FI_REGION_WORDS;
-    }
+    // several workgroups per try, one mailbox exchange per pick (see kmeans_farthest_init_multi_kernel).  Each call
+    // takes one of FI_SLOTS mailbox slots of its device; a slot is handed out again only once the event recorded
+    // behind its last user has completed (waited for if all slots are busy), so calls in flight on different streams
+    // never share or zero a live region.
+    std::lock_guard<std::mutex> lk(fi_mu);  // held over the launches: the slot's event must be recorded before a re-use
+    int dev = -1, slot = -1;
+    const int rc = fi_acquire(&dev, &slot);
+    if (rc != NIF_OK) return rc;
+    FiDevice& fd = fi_devs[dev];
+    unsigned long long* region = fd.base + (size_t)slot * FI_MAX_TRIES * FI_REGION_WORDS;
     int B = (N + 2047) / 2048;            // two neurons per lane where that fills <= 16 workgroups
     if (B > FI_MAX_WG) B = FI_MAX_WG;
     const int span = (N + B - 1) / B;
     const int ept = (span + 1023) / 1024;
+    const int inject = env_int("NIF_KMEANS_INIT_INJECT_TIMEOUT");  // tests: force the timeout path
     if (hipMemsetAsync(region, 0, (size_t)tries * FI_REGION_WORDS * sizeof(unsigned long long), st) != hipSuccess)
       return NIF_ERR_LAUNCH;
 #define NIF_FIM_GO(E)                                                                                                  \
   hipLaunchKernelGGL((kmeans_farthest_init_multi_kernel<E, GT>), dim3(B, tries), dim3(1024), 0, st, G, ldg, gd, nn, N, \
-                     k, fb, span, picks, assign, mind, region)
+                     k, fb, span, picks, assign, mind, region, inject)
     if (ept <= 1) NIF_FIM_GO(1);
     else if (ept <= 2) NIF_FIM_GO(2);
     else NIF_FIM_GO(4);
 #undef NIF_FIM_GO
-    return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+    // a try whose exchange timed out is redone by one workgroup; the others return at once
+    hipLaunchKernelGGL(kmeans_farthest_init_kernel<GT>, dim3(1, tries), dim3(1024), 0, st, G, ldg, gd, nn, N, k, fb, picks,
+                       assign, mind, fd.redo);
+    const bool ok = launch_ok();
+    fd.used[slot] = hipEventRecord(fd.done[slot], st) == hipSuccess;
+    if (!fd.used[slot]) (void)hipStreamSynchronize(st);  // no event to guard the slot: drain before it can be re-used
+    return ok ? NIF_OK : NIF_ERR_LAUNCH;
   }
   const int ept = (N + 1023) / 1024;
 #define NIF_FI_GO(E)                                                                                                   \
@@ -1363,7 +1425,7 @@ static int km_farthest_init(const GT* G, int64_t ldg, const double* gd, const do
   else if (ept <= 32) NIF_FI_GO(32);
   else
     hipLaunchKernelGGL(kmeans_farthest_init_kernel<GT>, dim3(1, tries), dim3(1024), 0, st, G, ldg, gd, nn, N, k, fb, picks,
-                       assign, mind);
+                       assign, mind, (unsigned*)nullptr);
 #undef NIF_FI_GO
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
@@ -1460,6 +1522,18 @@ static int km_repair_kf(int32_t* assign, double* nearest, const float* s, const 
 }
 
 }  // namespace nif
+
+extern "C" int nif_kmeans_farthest_init_redo_count(uint32_t* count_host, void* stream) {
+  if (!count_host) return NIF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(nif::fi_mu);
+  int dev = -1;
+  const int rc = nif::fi_device(&dev);
+  if (rc != NIF_OK) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(count_host, nif::fi_devs[dev].redo, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+    return NIF_ERR_LAUNCH;
+  return hipStreamSynchronize(st) == hipSuccess ? NIF_OK : NIF_ERR_LAUNCH;
+}
 
 extern "C" int nif_kmeans_farthest_init(const double* G, int64_t ldg, const double* nn, int N, int k, int first,
                                         int32_t* picks, int32_t* assign, double* mind, void* stream) {

@@ -18,6 +18,7 @@
 namespace nif {
 
 static inline size_t lq256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline unsigned grid_rows(int64_t rows) { return (unsigned)(rows < 1 ? 1 : (rows > 32768 ? 32768 : rows)); }  // grid y extent
 
 // idx[0 .. count) = indices i with G[i][i] > 0, ascending; count[0] = their number.  One workgroup.
 __global__ __launch_bounds__(1024) void lsq_live_kernel(const double* __restrict__ G, int64_t ldg, int d, int* __restrict__ idx,
@@ -70,9 +71,12 @@ __global__ void lsq_scale_rows_kernel(double* __restrict__ Z, int64_t ldz, const
 }
 
 // column scaling for norm_acts (fusion_utils.py:38-40): R[:, c] /= sqrt(na[c]); na[c] = 1 afterwards (second kernel)
+// (rows walk the grid's y extent with a stride: the dual form puts d, which nothing bounds, on this axis)
 __global__ void lsq_scale_cols_kernel(double* __restrict__ R, int64_t ldr, const double* __restrict__ na, int rows, int N) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-  if (c < N && r < rows) R[(size_t)r * ldr + c] /= sqrt(na[c]);
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const double nrm = sqrt(na[c]);
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) R[(size_t)r * ldr + c] /= nrm;
 }
 __global__ void lsq_ones_kernel(double* __restrict__ v, int N) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,8 +95,9 @@ __global__ void lsq_widen_kernel(const float* __restrict__ in, int64_t ldi, int6
 }
 
 __global__ void lsq_zero_kernel(double* __restrict__ W, int64_t ldw, int rows, int N) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-  if (c < N && r < rows) W[(size_t)r * ldw + c] = 0.0;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) W[(size_t)r * ldw + c] = 0.0;
 }
 
 struct LsqSolveWs {
@@ -167,7 +172,7 @@ extern "C" int nif_lsq_solve_f64(const double* G, int64_t ldg, const double* R, 
   if (hipStreamSynchronize(st) != hipSuccess) return NIF_ERR_LAUNCH;
   if (nl < 0 || nl > d) return NIF_ERR_LAUNCH;
   const dim3 tb(256);
-  if (nl < d) hipLaunchKernelGGL(lsq_zero_kernel, dim3((N + 255) / 256, d), tb, 0, st, W, ldw, d, N);
+  if (nl < d) hipLaunchKernelGGL(lsq_zero_kernel, dim3((N + 255) / 256, grid_rows(d)), tb, 0, st, W, ldw, d, N);
   if (nl == 0) return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;   // X = 0: pinv(X) = 0
   const double* Ge = G;
   int64_t lde = ldg;
@@ -186,7 +191,7 @@ extern "C" int nif_lsq_solve_f64(const double* G, int64_t ldg, const double* R, 
   double* Wout = nl < d ? Wc : W;
   const int64_t ldwo = nl < d ? (int64_t)N : ldw;
   if (K == 0) {
-    hipLaunchKernelGGL(lsq_zero_kernel, dim3((N + 255) / 256, d), tb, 0, st, W, ldw, d, N);
+    hipLaunchKernelGGL(lsq_zero_kernel, dim3((N + 255) / 256, grid_rows(d)), tb, 0, st, W, ldw, d, N);
     return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
   }
   // Z = V^T R (K x N), Z /= lam, W = V Z
@@ -281,7 +286,7 @@ extern "C" int nif_lsq_refit_f32(const float* X, int64_t ldx, int64_t m, int d, 
   if (rc != NIF_OK) return rc;
   const bool normalize = (flags & NIF_LSQ_NORMALIZE) != 0;
   if (normalize && !dual) {
-    hipLaunchKernelGGL(lsq_scale_cols_kernel, dim3((N + 255) / 256, d), tb, 0, st, R, ldr, na, d, N);
+    hipLaunchKernelGGL(lsq_scale_cols_kernel, dim3((N + 255) / 256, grid_rows(d)), tb, 0, st, R, ldr, na, d, N);
     hipLaunchKernelGGL(lsq_ones_kernel, dim3((N + 255) / 256), tb, 0, st, na, N);
   }
   if (!dual) {
@@ -307,7 +312,7 @@ extern "C" int nif_lsq_refit_f32(const float* X, int64_t ldx, int64_t m, int d, 
   hipLaunchKernelGGL(lsq_widen_kernel, dim3((d + 255) / 256, (unsigned)m), tb, 0, st, X, ldx, m, d, (const double*)nullptr,
                      X64, (int64_t)d);
   if (normalize) {  // after A64 took the norms: R and na in their normalised form
-    hipLaunchKernelGGL(lsq_scale_cols_kernel, dim3((N + 255) / 256, d), tb, 0, st, R, ldr, na, d, N);
+    hipLaunchKernelGGL(lsq_scale_cols_kernel, dim3((N + 255) / 256, grid_rows(d)), tb, 0, st, R, ldr, na, d, N);
     hipLaunchKernelGGL(lsq_ones_kernel, dim3((N + 255) / 256), tb, 0, st, na, N);
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
@@ -316,7 +321,7 @@ extern "C" int nif_lsq_refit_f32(const float* X, int64_t ldx, int64_t m, int d, 
   if (rc != NIF_OK) return rc;
   *rank_host = K;
   if (K == 0) {
-    hipLaunchKernelGGL(lsq_zero_kernel, dim3((N + 255) / 256, d), tb, 0, st, W, ldw, d, N);
+    hipLaunchKernelGGL(lsq_zero_kernel, dim3((N + 255) / 256, grid_rows(d)), tb, 0, st, W, ldw, d, N);
     return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
   }
   rc = nif_xty(U, mm, A64, N, mm, K, N, NIF_F64, NIF_F64, 0, Z, N, nullptr, nullptr, xws, w.xty_bytes, stream);  // U^T A

@@ -323,7 +323,7 @@ extern "C" int nif_sinkhorn_f32(const float* C, int64_t ldc, int n0, int n1, con
   // iterations are enqueued in batches; between batches the host reads the state word (the only synchronisations)
   const int batch = 50;
   int done = 0, n_it = 0;
-  prof_begin(NIF_PROF_KMEANS, st);  // shares the bandwidth-kernel slot (one span per call)
+  prof_begin(NIF_PROF_SINKHORN, st);  // one span per call
   while (n_it < max_iter && !done) {
     const int n = (max_iter - n_it) < batch ? (max_iter - n_it) : batch;
     for (int e = 0; e < n; ++e, ++n_it) {
@@ -335,12 +335,14 @@ extern "C" int nif_sinkhorn_f32(const float* C, int64_t ldc, int n0, int n1, con
     if (n_it < max_iter) {
       int state[4] = {0, 0, 0, 0};
       if (hipMemcpyAsync(state, ctl, sizeof(state), hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess)
+          hipStreamSynchronize(st) != hipSuccess) {
+        prof_end(NIF_PROF_SINKHORN, st);  // the span is closed on the error path too
         return NIF_ERR_LAUNCH;
+      }
       done = state[0] != 0 || state[3] != 0;
     }
   }
-  prof_end(NIF_PROF_KMEANS, st);
+  prof_end(NIF_PROF_SINKHORN, st);
   hipLaunchKernelGGL(sk_plan_kernel, dim3((unsigned)((cover + 255) / 256)), dim3(256), 0, st, K, ldk, n0, n1, ubuf, vbuf,
                      ctl, n_it, T, ldt, u_out, v_out, info);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;

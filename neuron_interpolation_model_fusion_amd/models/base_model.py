@@ -61,6 +61,8 @@ twin_copy.replay_init_draws = os.environ.get('NIF_FAST_TWIN_COPY', '0') != '1'
 
 
 class BaseModel(nn.Module, ABC):
+    # True on classes whose forward never writes into a tensor a hooked layer has seen (see register_hooks)
+    captures_may_alias = False
 
     def __init__(self, train_indices=None, val_indices=None):
         super().__init__()
@@ -137,17 +139,23 @@ class BaseModel(nn.Module, ABC):
     # -- activation capture (base_model.py:103-133) --------------------------------
     def register_hooks(self):
         names = {rep.layer: rep.name for rep in self.get_ordered_trainable_named_layers}
-        # The reference clones every captured tensor (base_model.py:110-118).  A clone only matters if something
-        # writes into the tensor after the hook has seen it, i.e. if the model holds an in-place module (ReLU(inplace=
-        # True), Dropout(inplace=True), ...): none of the reference's architectures does, so the captures alias the
-        # forward's own tensors (no copy pass, the same memory footprint as the clones had).
-        must_clone = any(getattr(m, 'inplace', False) for m in self.modules())
+        # The reference clones every captured tensor (base_model.py:110-118), and so does this class by default.  A
+        # clone only matters if something writes into the tensor after the hook has seen it (an in-place module, or a
+        # functional in-place op in forward()).  A model class whose forward is known to do neither sets
+        # `captures_may_alias = True` (VGG, MLPNet, ViT here): its captures then alias the forward's own tensors -- no
+        # copy pass -- and the tensors' version counters are kept, so that a write that happens anyway is reported
+        # when the capture is read instead of silently corrupting costs and refits.
+        alias = bool(getattr(type(self), 'captures_may_alias', False)) and \
+            not any(getattr(m, 'inplace', False) for m in self.modules())
+        self._capture_versions = {}
 
         def capture(module, inputs, output):
             name = names[module]
             x, y = inputs[0].detach(), output.detach()
-            self.layer_inputs[name] = x.clone() if must_clone else x
-            self.layer_outputs[name] = y.clone() if must_clone else y
+            if alias:
+                self._capture_versions[name] = (x._version, y._version)
+            self.layer_inputs[name] = x if alias else x.clone()
+            self.layer_outputs[name] = y if alias else y.clone()
 
         for rep in self.get_ordered_trainable_named_layers:
             self.handles[rep.name] = rep.layer.register_forward_hook(capture)
@@ -158,7 +166,13 @@ class BaseModel(nn.Module, ABC):
         self.handles.clear()
         self.layer_inputs.clear()
         self.layer_outputs.clear()
+        getattr(self, '_capture_versions', {}).clear()
 
     def get_inputs_and_preactivations(self, layer_idx):
         name = self.get_ordered_trainable_named_layers[layer_idx].name
-        return self.layer_inputs[name], self.layer_outputs[name]
+        x, y = self.layer_inputs[name], self.layer_outputs[name]
+        seen = getattr(self, '_capture_versions', {}).get(name)
+        if seen is not None and seen != (x._version, y._version):
+            raise RuntimeError(f'{type(self).__name__}: the captured activations of layer {name!r} were modified in place '
+                               f'after the hook saw them; set captures_may_alias = False on the class')
+        return x, y

@@ -6,6 +6,7 @@ from .base_model import BaseModel, WeightRepresentation, LevelRepresentation
 
 
 class MLPNet(BaseModel):
+    captures_may_alias = True  # forward() never writes into a tensor a hooked layer has seen
 
     def __init__(self, input_size, hidden_size, output_size, use_bias=True, use_activations=True,
                  train_indices=None, val_indices=None):

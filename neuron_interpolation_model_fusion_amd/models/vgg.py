@@ -12,6 +12,7 @@ from .base_model import BaseModel, WeightRepresentation, LevelRepresentation
 
 
 class VGG(BaseModel):
+    captures_may_alias = True  # forward() never writes into a tensor a hooked layer has seen
     cfg = {
         'VGG11': [64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
         'VGG11_3/2': [64, 'M', 192, 'M', 384, 384, 'M', 768, 768, 'M', 768, 768, 'M'],

@@ -73,6 +73,7 @@ class TransformerEncoder(nn.Module):
 
 
 class ViT(BaseModel):
+    captures_may_alias = True  # forward() never writes into a tensor a hooked layer has seen
 
     def __init__(self, in_c, num_classes=10, img_size=32, patch=8, dropout=0.0, depth=7, hidden=384,
                  mlp_hidden=384 * 4, head=8, embedder_separare_level=False, train_indices=None, val_indices=None):

@@ -324,7 +324,7 @@ def refit_gather(W0, W1, rowsrc=None, colsrc=None, alpha=1.0, beta=1.0, sp=1):
     return out.reshape(shape)
 
 
-PROF_XTY, PROF_LAP, PROF_KMEANS, PROF_EIGH_TRD = 0, 1, 2, 3
+PROF_XTY, PROF_LAP, PROF_KMEANS, PROF_EIGH_TRD, PROF_SINKHORN = 0, 1, 2, 3, 4
 
 
 def profile_enable(on=True, slots=None):
@@ -339,6 +339,14 @@ def profile_collect(slot):
     ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
     check(lib.nif_profile_collect(slot, ctypes.byref(ms), ctypes.byref(cnt)), 'nif_profile_collect')
     return ms.value, cnt.value
+
+
+def profile_collect_spans(slot, cap=1 << 16):
+    """Durations (ms, record order) of the spans recorded for a slot since the last collect, as a list (at most cap)."""
+    buf = (ctypes.c_float * cap)()
+    cnt = ctypes.c_int64(0)
+    check(lib.nif_profile_collect_spans(slot, buf, cap, ctypes.byref(cnt)), 'nif_profile_collect_spans')
+    return [float(buf[i]) for i in range(min(cap, cnt.value))]
 
 
 def profile_work(slot):
@@ -410,6 +418,15 @@ def eigh_kept(G, cutoff_rel):
                                     _ptr(ws), nbytes, _stream()), 'nif_eigh_kept_f64')
     K = kept.value
     return lam[:K], V[:, :K]
+
+
+def eigh_trd_launch_counts():
+    """{(mode, cpw, two): launches} of every tridiagonalisation step kernel since the process started (diagnostic for
+    the parity tests: which trd_step_kernel<CPW, TWO, MODE> instantiations a problem size actually ran)."""
+    arr = (ctypes.c_uint64 * 30)()
+    check(lib.nif_eigh_trd_launch_counts(arr), 'nif_eigh_trd_launch_counts')
+    cpws = (1, 2, 3, 4, 6)
+    return {(m, cpws[c], w): int(arr[(m * 5 + c) * 2 + w]) for m in range(3) for c in range(5) for w in range(2)}
 
 
 def ls_solve(X, A, normalize=False):
@@ -586,6 +603,14 @@ class KMeans:
             check(fn(_ptr(self.G), self.G.stride(0), *self._g, _ptr(self.nn), self.N, self.k, arr, T, _ptr(picks),
                      _ptr(assign), _ptr(mind), _stream()), 'nif_kmeans_farthest_init_batch' + self._sfx)
         return picks, assign
+
+    def farthest_init_redo_count(self):
+        """Tries of the multi-workgroup initialisation (N > 4096) that timed out in their exchange and were done again
+        by the one-workgroup kernel on this device since the process started (diagnostic; blocks)."""
+        n = ctypes.c_uint32(0)
+        with torch.cuda.device(self.dev):
+            check(lib.nif_kmeans_farthest_init_redo_count(ctypes.byref(n), _stream()), 'nif_kmeans_farthest_init_redo_count')
+        return n.value
 
     def assign_to_neurons(self, c0):
         with torch.cuda.device(self.dev):

@@ -1,0 +1,259 @@
+"""-m gpu: the symmetric eigensolver and the LS refit at the sizes BASELINE config 1 runs them (d = 1153,
+2305, 4609; m < d for layers 6-8), where the tridiagonalisation switches kernels (trd_step_kernel<CPW, TWO, MODE>:
+more column chunks per wave above a trailing width of 1024, every other step left unstored, a second row group in
+flight).  The checker is f64 numpy / torch (CPU LAPACK, or the defining identities evaluated with torch matmuls):
+residual, orthogonality, kept count, the spectral function V diag(1/lambda) V^T the refit applies, and pinv(rcond).
+Reference call sites: hf_kf.py:213,377 (`torch.linalg.pinv(X)`), :233-234,397 (`pinv @ acts`)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+EPS32 = 1.1920928955078125e-07
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from neuron_interpolation_model_fusion_amd import ops
+    return ops
+
+
+def _reflect(G, u):
+    """H G H with H = I - 2 u u^T (u a unit vector), in place of two n^3 products."""
+    Gu = G @ u
+    uGu = float(u @ Gu)
+    G -= 2.0 * torch.outer(u, Gu)
+    G -= 2.0 * torch.outer(Gu, u)
+    G += 4.0 * uGu * torch.outer(u, u)
+    return G
+
+
+def _known_spectrum(n, lam, seed, device='cuda'):
+    """(G, Q) with G = Q diag(lam) Q^T and Q = H4 H3 H2 H1 (random Householder reflectors): a dense symmetric matrix
+    whose eigenpairs are known to rounding without running any eigensolver."""
+    g = torch.Generator().manual_seed(seed)
+    G = torch.diag(torch.as_tensor(lam, dtype=torch.float64).to(device))
+    Q = torch.eye(n, dtype=torch.float64, device=device)
+    for _ in range(4):
+        u = torch.randn(n, generator=g, dtype=torch.float64).to(device)
+        u /= u.norm()
+        _reflect(G, u)                      # G <- H G H
+        Q -= 2.0 * torch.outer(u, u @ Q)    # Q <- H Q
+    return 0.5 * (G + G.T), Q
+
+
+def _spectra(n):
+    rng = np.random.default_rng(n)
+    graded = np.sort(np.logspace(0, -16, n))                        # the cutoff cuts it in the middle
+    k1, k2, kz = n // 4, n // 4, n // 8
+    clustered = np.sort(np.r_[np.zeros(kz), np.linspace(0.01, 0.4, n - k1 - k2 - kz), np.full(k2, 0.5), np.ones(k1)])
+    lowrank = np.sort(np.r_[np.zeros(n - n // 3), 1.0 + rng.random(n // 3)])   # rank n / 3, exact null space
+    return {'graded': (graded, 3.3e-9), 'clustered': (clustered, 1e-6), 'lowrank': (lowrank, 1e-9)}
+
+
+def _check_eigh(ops, G, cutoff, lam_true=None, Q=None, tag=''):
+    """Runs ops.eigh_kept(G, cutoff) and checks it from the definitions; returns (lam, V)."""
+    n = G.shape[0]
+    lam, V = ops.eigh_kept(G, cutoff)
+    K = lam.shape[0]
+    scale = float(G.abs().max()) * n
+    if lam_true is not None:
+        lam_true = torch.as_tensor(lam_true, dtype=torch.float64).cuda()
+        keep = lam_true > cutoff * lam_true.max()
+        # the test spectra leave a gap of many orders of rounding around the cutoff
+        assert K == int(keep.sum()), (tag, K, int(keep.sum()))
+        assert float((lam - lam_true[keep]).abs().max()) <= 1e-13 * scale, tag
+    assert V.shape == (n, K)
+    assert float((V.T @ V - torch.eye(K, dtype=torch.float64, device='cuda')).abs().max()) < 1e-9, tag
+    assert float((G @ V - V * lam).abs().max()) <= 2e-14 * scale, tag
+    if Q is not None and K > 0:
+        Qk = Q[:, keep]
+        P = (V / lam) @ V.T
+        Pref = (Qk / lam_true[keep]) @ Qk.T
+        # 1 / lambda near the cutoff magnifies the rounding of G itself (eps64 * |G|) by 1 / cutoff
+        tol = max(1e-7, 200 * 2.2e-16 / cutoff)
+        assert float((P - Pref).abs().max()) <= tol * float(Pref.abs().max()), tag
+    return lam, V
+
+
+@pytest.mark.parametrize('n', [1153, 1600, 2305, 4609, 6143])
+@pytest.mark.parametrize('kind', ['graded', 'clustered', 'lowrank'])
+def test_eigh_kept_known_spectrum_with_active_cutoff(ops, n, kind):
+    if n == 6143 and kind != 'clustered':
+        pytest.skip('one spectrum at the odd size next to NIF_EIGH_MAX_N')
+    lam_true, cutoff = _spectra(n)[kind]
+    assert np.abs(lam_true / lam_true.max() - cutoff).min() > 1e-3 * cutoff, 'spectrum has an eigenvalue on the cutoff'
+    G, Q = _known_spectrum(n, lam_true, seed=n)
+    # the construction itself, so that a wrong Q cannot hide behind the solver: G Q = Q diag(lam)
+    lt = torch.as_tensor(lam_true).cuda()
+    assert float((G @ Q - Q * lt).abs().max()) < 1e-12 * max(1.0, float(lt.max()))
+    _check_eigh(ops, G, cutoff, lam_true, Q, tag=f'{kind}{n}')
+
+
+def _relu_gram(m, d, seed, dead=13, dup_rows=0):
+    """A ReLU design matrix with dead columns and a ones column, as the refit sees them (rank-deficient);
+    dup_rows: that many samples repeated exactly, which makes the dual form (m < d) rank-deficient too."""
+    g = torch.Generator().manual_seed(seed)
+    r = max(8, d // 6)
+    F = torch.randn(m, r, generator=g) @ torch.randn(r, d - 1, generator=g) / r ** 0.5 + 0.05 * torch.randn(m, d - 1, generator=g)
+    X = torch.cat([F.clamp_min(0), torch.ones(m, 1)], dim=1)
+    X[:, ::dead] = 0.0
+    if dup_rows:
+        X[m - dup_rows:] = X[:dup_rows]
+    return X
+
+
+@pytest.mark.parametrize('m,d', [(3000, 1153), (4000, 2305)])
+def test_eigh_kept_relu_gram_matches_numpy(ops, m, d):
+    X = _relu_gram(m, d, seed=d)
+    G = (X.double().T @ X.double())
+    cutoff = (max(m, d) * EPS32) ** 2
+    lam_ref, U = np.linalg.eigh(G.numpy())
+    keep = lam_ref > cutoff * lam_ref[-1]
+    gap = np.abs(lam_ref / lam_ref[-1] - cutoff).min()
+    assert gap > 1e-4 * cutoff, 'test matrix has an eigenvalue on the cutoff'
+    lam, V = _check_eigh(ops, G.cuda(), cutoff, tag=f'relu{d}')
+    assert lam.shape[0] == int(keep.sum())
+    np.testing.assert_allclose(lam.cpu().numpy(), lam_ref[keep], rtol=0, atol=1e-12 * lam_ref[-1] * d)
+    P = ((V / lam) @ V.T).cpu().numpy()
+    Pref = (U[:, keep] / lam_ref[keep]) @ U[:, keep].T
+    assert np.abs(P - Pref).max() <= 1e-7 * np.abs(Pref).max()
+
+
+_VARIANTS = [{}, {'NIF_EIGH_TRD_KP': '1'}, {'NIF_EIGH_TRD_ONE_GROUP': '1'},
+             {'NIF_EIGH_TRD_KP': '1', 'NIF_EIGH_TRD_ONE_GROUP': '1'}]
+
+
+@pytest.mark.parametrize('n', [1600, 2305, 3100, 4609, 5000])
+def test_eigh_kernel_variants_agree_to_rounding(ops, n, monkeypatch):
+    """The same problem through the default kernel schedule, with every step storing the matrix (NIF_EIGH_TRD_KP=1),
+    with the single-prefetch kernels (NIF_EIGH_TRD_ONE_GROUP=1) and with both: four different sets of
+    trd_step_kernel instantiations, each checked from the definitions and against each other."""
+    lam_true, cutoff = _spectra(n)['clustered']
+    G, Q = _known_spectrum(n, lam_true, seed=7 * n)
+    results = []
+    for env in _VARIANTS:
+        for key in ('NIF_EIGH_TRD_KP', 'NIF_EIGH_TRD_ONE_GROUP'):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        before = ops.eigh_trd_launch_counts()
+        lam, V = _check_eigh(ops, G, cutoff, lam_true, Q, tag=f'{n}{env}')
+        after = ops.eigh_trd_launch_counts()
+        ran = {key for key in after if after[key] > before[key]}
+        assert sum(after.values()) - sum(before.values()) == n - 2   # one launch per column
+        if env.get('NIF_EIGH_TRD_KP'):
+            assert all(mode == 0 for mode, _, _ in ran), ran
+        elif n > 1030:
+            assert any(mode == 1 for mode, _, _ in ran) and any(mode == 2 for mode, _, _ in ran), ran
+        if env.get('NIF_EIGH_TRD_ONE_GROUP'):
+            assert all(two == 0 for _, _, two in ran), ran
+        results.append((lam, (V / lam) @ V.T))
+    scale = float(G.abs().max()) * n
+    for lam, P in results[1:]:
+        assert float((lam - results[0][0]).abs().max()) <= 1e-13 * scale
+        assert float((P - results[0][1]).abs().max()) <= 1e-8 * float(results[0][1].abs().max())
+
+
+def test_every_tridiagonalisation_kernel_of_the_table_has_run(ops, monkeypatch):
+    """After one pass at n = 4609 under the four schedules, every instantiation the dispatch can select has been
+    launched (and so checked, by the assertions of _check_eigh); the table holds no kernel that no size reaches."""
+    lam_true, cutoff = _spectra(4609)['lowrank']
+    G, Q = _known_spectrum(4609, lam_true, seed=3)
+    for env in _VARIANTS:
+        for key in ('NIF_EIGH_TRD_KP', 'NIF_EIGH_TRD_ONE_GROUP'):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        _check_eigh(ops, G, cutoff, lam_true, Q, tag=str(env))
+    counts = ops.eigh_trd_launch_counts()
+    reachable = ({(0, c, 0) for c in (1, 2, 3, 4, 6)} | {(0, c, 1) for c in (2, 3, 4)} |
+                 {(1, c, w) for c in (2, 3, 4) for w in (0, 1)} |
+                 {(2, c, w) for c in (2, 3) for w in (0, 1)} | {(2, 4, 0)})
+    never = sorted(key for key in reachable if counts[key] == 0)
+    assert not never, f'kernels never launched: {never}'
+    extra = sorted(key for key, c in counts.items() if c and key not in reachable)
+    assert not extra, f'kernels launched that the test does not expect: {extra}'
+
+
+def _pinv_reference(X, A, rtol):
+    X64 = X.double()
+    U, S, Vh = torch.linalg.svd(X64, full_matrices=False)
+    keep = S > rtol * S[0]
+    gap = float((S / S[0] - rtol).abs().min())
+    W = (Vh[keep].T / S[keep]) @ (U[:, keep].T @ A.double())
+    return W, int(keep.sum()), gap
+
+
+@pytest.mark.parametrize('m,d', [(6400, 4609), (25600, 2305), (1600, 4609), (400, 513)])
+def test_ls_solve_at_vgg11_layer_sizes_matches_f64_pinv(ops, m, d):
+    """W = pinv(X) A at the (m, d) of VGG11's layers 3-8 -- primal form for m >= d, dual (minimum-norm)
+    form for m < d -- against the f64 SVD pseudo-inverse with torch.linalg.pinv's f32 cutoff."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    X = _relu_gram(m, d, seed=m + d, dup_rows=m // 16 if m < d else 0)
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(m, 12, generator=g)
+    rtol = max(m, d) * EPS32
+    ref, rank, gap = _pinv_reference(X, A, rtol)
+    assert gap > 1e-4 * rtol, 'test matrix has a singular value on the cutoff'
+    sol = ops.ls_solve(X.cuda(), A.cuda())
+    assert sol['rank'] == rank
+    assert rank < min(m, d), 'the cutoff is meant to be active'
+    W = sol['W'].cpu()
+    assert float((W - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+
+
+def test_c1_kf_fusion_every_layer_refit_checked(ops):
+    """Config 1 end to end (KF of four random-init VGG11s, 400 samples): every layer's LS refit inside the running
+    fusion is checked -- rank against the f64 singular values of the very design matrix, and the normal-equation
+    residual X^T (A - X W), which for W = pinv_rcond(X) A is confined to the dropped singular directions:
+    |X^T (a - X w)| <= sigma_cut * |a| per column."""
+    from neuron_interpolation_model_fusion_amd.fusion_algorithms import hf_kf
+    from neuron_interpolation_model_fusion_amd.models import VGG
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    dev = torch.device('cuda', 0)
+    models = []
+    for k in range(4):
+        torch.manual_seed(100 + k)
+        models.append(VGG('VGG11', 10, (3, 32, 32), batch_norm=False, use_bias=True, use_activations=False).eval().to(dev))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    X = torch.randn(400, 3, 32, 32, device=dev)
+    real = ops.ls_solve
+    seen = []
+
+    def checked(Xd, A, normalize=False):
+        sol = real(Xd, A, normalize=normalize)
+        m, d = Xd.shape
+        rtol = max(m, d) * EPS32
+        X64 = Xd.double()
+        # singular values through the smaller Gram in f64 on the CPU (LAPACK): sigma^2 = eigenvalues
+        Gs = (X64.T @ X64 if m >= d else X64 @ X64.T).cpu().numpy()
+        ev = np.linalg.eigvalsh(Gs)
+        sig = np.sqrt(np.clip(ev, 0, None))
+        rank = int((sig > rtol * sig[-1]).sum())
+        # eigenvalues of the Gram resolve sigma only to sqrt(eps64) * sigma_max: count the ones that close to the cutoff
+        unsure = int((np.abs(sig - rtol * sig[-1]) < 3e-8 * sig[-1]).sum())
+        assert abs(sol['rank'] - rank) <= unsure, (m, d, sol['rank'], rank, unsure)
+        A64 = A.double()
+        resid = X64.T @ (A64 - X64 @ sol['W'])
+        bound = rtol * sig[-1] * A64.norm(dim=0) * (1 + 1e-6) + 1e-9 * sig[-1] * A64.norm(dim=0)
+        assert bool((resid.norm(dim=0) <= bound).all()), (m, d, float((resid.norm(dim=0) / bound).max()))
+        # and the fit is no worse than the f64 pinv's on the kept subspace: |A - X W| matches the f64 residual norm
+        seen.append((m, d, sol['rank'], rank))
+        return sol
+
+    hf_kf.ops.ls_solve = checked
+    try:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            fused = hf_kf.LSFusion(models).fuse(X, None, 'k_means')
+    finally:
+        hf_kf.ops.ls_solve = real
+    assert [(m, d) for m, d, _, _ in seen] == [(409600, 28), (102400, 577), (25600, 1153), (25600, 2305), (6400, 2305),
+                                               (6400, 4609), (1600, 4609), (1600, 4609), (400, 513)]
+    for p in fused.parameters():
+        assert bool(torch.isfinite(p).all())

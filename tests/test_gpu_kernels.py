@@ -679,6 +679,57 @@ def test_kmeans_farthest_init_many_equals_one_by_one(ops, N, k, T, gdtype):
 
 
 @pytest.mark.parametrize('gdtype', [torch.float64, torch.float32])
+def test_kmeans_farthest_init_exchange_timeout_is_redone_not_returned_partial(ops, gdtype, monkeypatch):
+    """The multi-workgroup initialisation (N > 4096) with a timeout forced into its exchange
+    (NIF_KMEANS_INIT_INJECT_TIMEOUT): every try falls to the one-workgroup kernel queued behind it inside the same
+    call, the caller gets the complete picks / labels, and the device counter says what happened."""
+    N, k, T = 6000, 40, 3
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(24, N, generator=g).double()
+    G = ((0.9 * A).T @ (0.9 * A)).to(gdtype).cuda()
+    nn = (A * A).sum(0).cuda()
+    km = ops.KMeans(G, nn, torch.ones(N).cuda(), k)
+    firsts = [3, 4100, 5999]
+    picks, assign = km.farthest_init_many(firsts)
+    assert int(picks.min()) >= 0
+    before = km.farthest_init_redo_count()
+    monkeypatch.setenv('NIF_KMEANS_INIT_INJECT_TIMEOUT', '1')
+    picks2, assign2 = km.farthest_init_many(firsts)
+    p1, a1 = km.farthest_init(firsts[1])
+    monkeypatch.delenv('NIF_KMEANS_INIT_INJECT_TIMEOUT')
+    assert km.farthest_init_redo_count() - before == T + 1
+    assert torch.equal(picks, picks2) and torch.equal(assign, assign2)
+    assert torch.equal(picks[1], p1) and torch.equal(assign[1], a1)
+    picks3, _ = km.farthest_init_many(firsts)          # and the next call is undisturbed
+    assert torch.equal(picks, picks3)
+    assert km.farthest_init_redo_count() - before == T + 1
+
+
+def test_kmeans_farthest_init_calls_in_flight_on_many_streams(ops):
+    """More multi-workgroup initialisations in flight (one per stream) than the library has mailbox slots: a slot is
+    handed out again only behind its last user's event, so every call gets what it gets alone."""
+    N, k = 5000, 24
+    g = torch.Generator().manual_seed(6)
+    A = torch.randn(16, N, generator=g).double()
+    G = ((0.9 * A).T @ (0.9 * A)).float().cuda()
+    nn = (A * A).sum(0).cuda()
+    km = ops.KMeans(G, nn, torch.ones(N).cuda(), k)
+    firsts = list(range(0, 4000, 200))     # 20 calls
+    alone = [km.farthest_init(f) for f in firsts]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in firsts]
+    got = []
+    kms = [ops.KMeans(G, nn, km.s, k) for _ in firsts]   # `mind` scratch of its own per call in flight
+    torch.cuda.synchronize()
+    for f, st, kmi in zip(firsts, streams, kms):
+        with torch.cuda.stream(st):
+            got.append(kmi.farthest_init(f))
+    torch.cuda.synchronize()
+    for (p0, a0), (p1, a1) in zip(alone, got):
+        assert torch.equal(p0, p1) and torch.equal(a0, a1)
+
+
+@pytest.mark.parametrize('gdtype', [torch.float64, torch.float32])
 def test_kmeans_batched_tries_equal_one_by_one(ops, gdtype):
     """lloyd_step_many / repair_kf_many over a subset of tries: the rows of the single-problem calls, bit for bit."""
     N, k, m, T = 700, 90, 48, 5

@@ -196,6 +196,47 @@ def test_hook_capture_aliases_unless_the_model_has_an_inplace_module():
     m.remove_hooks()
 
 
+def test_hook_capture_clones_by_default_and_reports_inplace_writes_on_aliasing_classes():
+    """A BaseModel subclass that does not opt in gets the reference's clones (base_model.py:110-118), so a functional
+    in-place op in its forward cannot corrupt the captures; a class that opted in and is written to anyway raises when
+    the capture is read."""
+    import pytest
+    import torch
+    import torch.nn.functional as F
+    from neuron_interpolation_model_fusion_amd.models import MLPNet
+
+    class InplaceMLP(MLPNet):
+        captures_may_alias = False
+
+        def forward(self, x):
+            h = self.level1(x)
+            F.relu(h, inplace=True)     # functional in-place op: no module attribute gives it away
+            return self.level2(h)
+
+    torch.manual_seed(0)
+    m = InplaceMLP(12, 16, 4, use_bias=True, use_activations=False).eval()
+    x = torch.randn(5, 1, 3, 4)
+    ref = m.get_ordered_trainable_named_layers[0].layer(x.flatten(1))
+    m.register_hooks()
+    with torch.no_grad():
+        m(x)
+    pre0 = m.get_inputs_and_preactivations(0)[1]
+    assert torch.allclose(pre0, ref) and bool((pre0 < 0).any())   # the clone kept the pre-activations
+    m.remove_hooks()
+
+    class WronglyAliasing(InplaceMLP):
+        captures_may_alias = True
+
+    torch.manual_seed(0)
+    w = WronglyAliasing(12, 16, 4, use_bias=True, use_activations=False).eval()
+    w.register_hooks()
+    with torch.no_grad():
+        w(x)
+    with pytest.raises(RuntimeError, match='modified in place'):
+        w.get_inputs_and_preactivations(0)
+    w.remove_hooks()
+
+
 def test_alf_flatten_and_join_equals_flatten_normalise_concatenate():
     """ALFusion._flatten_and_join writes each model's block straight into the joined matrices; the values are those of
     the reference's separate steps (alf.py:104-115, 181-189), bit for bit."""

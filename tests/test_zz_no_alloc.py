@@ -46,20 +46,17 @@ def test_static_scratch_entry_point_equals_the_workspace_entry_point():
     lib = _lib.lib
     dev = torch.device('cuda', 0)
     with torch.cuda.device(dev):
-        alloc_calls = []
         for flags in (0, _lib.NIF_LAP_SCIPY_ORDER):
             # first a large problem, then a smaller one right after it on the same stream
             for n, seed, ties in ((1500, 1, False), (333, 2, True), (2048, 3, False), (64, 4, False), (1, 5, False)):
                 C = _cost(n, seed, dev, ties)
                 for want_duals in (True, False):
                     ref = _solve(lib, C, flags, False, want_duals)
-                    before = torch.cuda.memory_stats(dev).get('allocation.all.allocated', 0)
                     got = _solve(lib, C, flags, True, want_duals)
                     assert torch.equal(got[0], ref[0]), (flags, n, want_duals)
                     assert sorted(got[0].tolist()) == list(range(n))
                     if want_duals:
                         assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
-                    alloc_calls.append(before)
         # two back-to-back launches without a host sync in between (stream order protects the shared scratch)
         C1, C2 = _cost(900, 6, dev), _cost(200, 7, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -70,6 +67,35 @@ def test_static_scratch_entry_point_equals_the_workspace_entry_point():
         torch.cuda.synchronize()
         assert torch.equal(c1, _solve(lib, C1, 0, False, False)[0])
         assert torch.equal(c2, _solve(lib, C2, 0, False, False)[0])
+
+
+def test_static_scratch_entry_point_allocates_no_device_memory():
+    """What the entry point is for: after a warm-up call (code objects loaded, the scratch symbol resolved) further
+    calls leave the device's free memory and torch's allocation counter exactly where they were, in both solver modes
+    and with a smaller problem after a larger one."""
+    from neuron_interpolation_model_fusion_amd import _lib
+    lib = _lib.lib
+    dev = torch.device('cuda', 0)
+    with torch.cuda.device(dev):
+        problems = [(_cost(n, 10 + n, dev), torch.empty(n, dtype=torch.int32, device=dev)) for n in (2048, 700, 64)]
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def run_all():
+            for flags in (0, _lib.NIF_LAP_SCIPY_ORDER):
+                for C, col in problems:
+                    n = C.shape[0]
+                    assert lib.nif_lap_solve_f32_static(_p(C), n, n, flags, _p(col), None, None, None, st) == 0
+            torch.cuda.synchronize()
+
+        run_all()  # warm-up
+        free0 = torch.cuda.mem_get_info(dev)[0]
+        count0 = torch.cuda.memory_stats(dev).get('allocation.all.allocated', 0)
+        for _ in range(3):
+            run_all()
+        assert torch.cuda.mem_get_info(dev)[0] == free0
+        assert torch.cuda.memory_stats(dev).get('allocation.all.allocated', 0) == count0
+        for C, col in problems:
+            assert sorted(col.tolist()) == list(range(C.shape[0]))
 
 
 def test_static_scratch_entry_point_rejects_sizes_beyond_its_maximum():
