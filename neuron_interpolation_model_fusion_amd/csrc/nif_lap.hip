@@ -353,6 +353,300 @@ __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restri
   if (tid == 0) stats[0] = step;  // Dijkstra steps taken (work counter, read by tools/lap_bench.py)
 }
 
+// ---- augmenting row reduction: the auction with zero slack of Jonker-Volgenant's initialisation, one workgroup ----
+// The greedy start leaves about a third of the rows of an unrelated instance free, and each of them costs a
+// shortest-path search of dozens to hundreds of Dijkstra steps (one dependent chain of ~0.9 us per step).  This phase
+// empties most of that list first.  A free row i bids for its best column j1 (smallest reduced cost r_j = C[i][j] -
+// v[j]): the price v[j1] drops by gamma = second-best - best, so that the row's best and second-best columns tie --
+// its new edge stays tight, v stays dual feasible (prices only ever fall), exact complementary slackness is kept --
+// and the previous owner of j1, if any, is free now and bids next: a chain that ends at a free column.  Sixteen
+// chains run side by side, one per wave, in lock-step passes: bids of one pass are formed from the same prices; per
+// column the largest gamma wins (lowest wave on ties) and the losers bid again with the same row.  gamma = 0 (costs
+// are f32, so reduced costs live on a lattice and exact ties do occur) is accepted for an occupied column too, up to
+// max_wait times in a row per chain: the owner it frees usually answers with a positive bid that breaks the tie; a
+// chain of zero bids that goes on (structural ties, e.g. duplicated columns) leaves its row to the augmenting phase.
+// The phase ends when the list of free rows is handed out and at most min_chains chains are left (the tail is no
+// faster per bid than a Dijkstra step), or after max_passes.  Whatever is still free goes to lap_augment_kernel as
+// before, from much better duals: unrelated activations, n = 384: 8958 Dijkstra steps / 7.2 ms without this phase,
+// 413 passes + 1479 steps / 2.0 ms with it; n = 1024: 36.7 -> 13.7 ms; n = 2048: 141 -> 51 ms
+// (profiles/r3_b_lap_arr_sweep.txt).  A pass costs ~1.5 us: the sixteen waves share one CU's four SIMDs, and a bid
+// is ~250 dependent vector instructions (f64 scan of the row, two wave-wide minima, the exchange).
+// Nothing in a pass waits for global memory: a wave keeps the cost row of its bidder in registers (CPT columns per
+// lane; CPT = 0 re-reads the row every pass, n > 1024), and as soon as it knows its best column it requests the row
+// of that column's owner -- the row that bids next if the bid wins -- into a second register set.  A wave that takes
+// a new row from the list of free rows sits one pass out while the row arrives.  Rows are handed out by wave order
+// from flags every wave reads, so the run is deterministic.  v / row4col / the list live in LDS; col4row is rebuilt at
+// the end.
+constexpr int ARR_W = 16;
+
+template <int CPT>
+__global__ __launch_bounds__(1024) void lap_arr_kernel(const float* __restrict__ C, int64_t ldc, int n,
+                                                       double* __restrict__ u, double* __restrict__ vg,
+                                                       int* __restrict__ col4row_g, int* __restrict__ row4col_g,
+                                                       int* __restrict__ stats, int max_passes, int min_chains,
+                                                       int max_wait) {
+  extern __shared__ __attribute__((aligned(16))) int lap_sm[];
+  double* v = reinterpret_cast<double*>(lap_sm);
+  int* row4col = reinterpret_cast<int*>(v + n);
+  int* queue = row4col + n;
+  double* bid_gamma = reinterpret_cast<double*>(queue + n + (n & 1));
+  int* bid_col = reinterpret_cast<int*>(bid_gamma + ARR_W);
+  int* flags = bid_col + ARR_W;
+  int* ctl = flags + ARR_W;  // per-wave counts of a compaction
+
+  const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = T >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the per-wave state below stays in SGPRs
+  constexpr unsigned NONE = 0xffffffffu;
+  constexpr int R = CPT > 0 ? CPT : 1;
+
+  // free rows, ascending, into `queue` (also used for the final pass over the rows still free); returns their number
+  auto compact_free = [&]() -> int {
+    int total = 0;
+    for (int base = 0; base < n; base += T) {
+      const int r = base + tid;
+      const bool fr = r < n && col4row_g[r] == -1;
+      const unsigned long long m = __ballot(fr);
+      if (lane == 0) ctl[wave] = __popcll(m);
+      __syncthreads();
+      int before = 0, all = 0;
+      for (int w = 0; w < nw; ++w) {
+        const int c = ctl[w];
+        if (w < wave) before += c;
+        all += c;
+      }
+      if (fr) queue[total + before + __popcll(m & ((1ull << lane) - 1ull))] = r;
+      total += all;
+      __syncthreads();
+    }
+    return total;
+  };
+
+  for (int j = tid; j < n; j += T) {
+    v[j] = vg[j];
+    row4col[j] = row4col_g[j];
+  }
+  const int total = compact_free();  // ends with a barrier: v / row4col / queue are visible
+
+  float bufA[R], bufB[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) bufA[q] = bufB[q] = 0.f;
+  auto request_row = [&](int row, float* buf) __attribute__((always_inline)) {  // clamped addresses: every load in flight, nothing to wait behind
+    const float* __restrict__ crow = C + (int64_t)row * ldc;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int j = lane + 64 * q;
+      buf[q] = crow[j < n ? j : n - 1];
+    }
+  };
+
+  int cur = -1;    // the row this wave bids for
+  int state = 0;   // 0: no row, 1: row requested this pass (bids from the next pass on), 2: bidding
+  int waited = 0;  // passes in a row in which this wave's bid was a zero bid for an occupied column
+  int pending = 0; // bufB holds the bidder's row (requested during the previous pass): move it over before use
+  int next = 0;    // entries of the list handed out so far (the same number in every wave)
+  unsigned need = (1u << ARR_W) - 1u;  // waves that want a row (the same mask in every wave)
+  int passes = 0;
+#ifdef NIF_LAP_ARR_TIMING
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tm = clock64();
+#define NIF_ARR_MARK(k) do { const long long t_ = clock64(); tacc[k] += t_ - tm; tm = t_; } while (0)
+#else
+#define NIF_ARR_MARK(k) do { } while (0)
+#endif
+
+  while (passes < max_passes && !(need == (1u << ARR_W) - 1u && next >= total)) {  // uniform over the block
+    if ((need >> wave) & 1u) {
+      const int at = next + __popc(need & ((1u << wave) - 1u));
+      if (at < total) {
+        cur = __builtin_amdgcn_readfirstlane(queue[at]);
+        state = CPT > 0 ? 1 : 2;
+        pending = 0;
+        if (CPT > 0) request_row(cur, bufA);  // not waited for here: the wave sits this pass out
+      }
+    }
+    next += __popc(need);
+    if (next > total) next = total;
+    NIF_ARR_MARK(0);
+
+    const bool bidding = state == 2;
+    int j1 = -1, prev = -1;
+    double g = 0.0;
+    if (bidding) {
+      double b1 = INFINITY, b2 = INFINITY;
+      int jl = INT_MAX;
+      // branch-free: a guarded LDS read or a branch per column would serialise the columns of a lane (one LDS
+      // round trip each); r = +inf for the columns past n
+      auto take = [&](float c, double vj, int j) __attribute__((always_inline)) {
+        const double r = j < n ? (double)c - vj : INFINITY;
+        const bool lt1 = r < b1, lt2 = r < b2;  // strict: the lowest column of a lane keeps a tie, the other copy
+        b2 = lt1 ? b1 : (lt2 ? r : b2);         // becomes the second best
+        b1 = lt1 ? r : b1;
+        jl = lt1 ? j : jl;
+      };
+      if (CPT > 0) {
+        if (pending) {  // the wait for last pass's request lands here, a whole pass after it was issued
+#pragma unroll
+          for (int q = 0; q < R; ++q) bufA[q] = bufB[q];
+          pending = 0;
+        }
+#ifdef NIF_LAP_ARR_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NIF_ARR_MARK(1);
+#endif
+        double vj[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int j = lane + 64 * q;
+          vj[q] = v[j < n ? j : n - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) take(bufA[q], vj[q], lane + 64 * q);
+      } else {
+        const float* __restrict__ crow = C + (int64_t)cur * ldc;
+        for (int t0 = 0; t0 < n; t0 += 512) {
+          float c[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int j = t0 + q * 64 + lane;
+            c[q] = crow[j < n ? j : n - 1];
+          }
+          double vj[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int j = t0 + q * 64 + lane;
+            vj[q] = v[j < n ? j : n - 1];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(c[q]));
+#pragma unroll
+          for (int q = 0; q < 8; ++q) take(c[q], vj[q], t0 + q * 64 + lane);
+        }
+      }
+      // wave-wide best (lowest column on ties) through the ordered-integer minima, then the second best: the minimum
+      // over the best lane's second and everybody else's best
+      const unsigned long long o1 = jl == INT_MAX ? ~0ull : f64_to_ordered(b1 + 0.0);
+      const unsigned hi = (unsigned)(o1 >> 32), lo = (unsigned)o1;
+      const unsigned whi = wave_min_u32(hi);
+      bool holder = hi == whi;
+      unsigned long long m = __ballot(holder);
+      if (whi != NONE && (m & (m - 1))) {
+        const unsigned wlo = wave_min_u32(holder ? lo : NONE);
+        holder = holder && lo == wlo;
+        m = __ballot(holder);
+        if (m & (m - 1)) {
+          const unsigned wj = wave_min_u32(holder ? (unsigned)jl : NONE);
+          holder = holder && (unsigned)jl == wj;
+          m = __ballot(holder);
+        }
+      }
+      if (whi != NONE) {
+        const int poster = __ffsll(m) - 1;
+        const double w2 = wave_min_f64(lane == poster ? b2 : b1);
+        j1 = __builtin_amdgcn_readlane(jl, poster);
+        const double w1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b1), poster),
+                                           __builtin_amdgcn_readlane(__double2loint(b1), poster));
+        g = w2 - w1;
+        prev = __builtin_amdgcn_readfirstlane(row4col[j1]);
+        if (CPT > 0 && prev >= 0) request_row(prev, bufB);  // the row that bids next if this bid wins
+      }
+    }
+    NIF_ARR_MARK(2);
+    if (lane == 0) {
+      bid_col[wave] = j1;
+      bid_gamma[wave] = g;
+    }
+    __syncthreads();
+    NIF_ARR_MARK(3);
+
+    int flag = 0;  // 1: wants a row, 2: a bid was accepted
+    if (bidding && j1 >= 0) {
+      const int oc = lane < ARR_W ? bid_col[lane] : -1;
+      const double og = lane < ARR_W ? bid_gamma[lane] : 0.0;
+      const bool lost = __ballot(lane < ARR_W && lane != wave && oc == j1 && (og > g || (og == g && lane < wave))) != 0ull;
+      if (!lost) {
+        const int finite = __builtin_amdgcn_readfirstlane((int)(g < INFINITY));  // 0 for +inf (one finite entry) / NaN
+        const int positive = __builtin_amdgcn_readfirstlane((int)(g > 0.0));
+        // a zero bid for an occupied column is accepted too, a few times in a row: the owner it frees usually answers
+        // with a positive bid for the same column, which breaks the tie the row sat on
+        if ((finite && positive) || prev == -1 || (finite && waited < max_wait)) {
+          if (!positive && prev >= 0) ++waited;
+          else waited = 0;
+          if (lane == 0) {
+            if (finite) v[j1] -= g;
+            row4col[j1] = cur;  // col4row is rebuilt from row4col at the end: no global store inside the loop
+          }
+          flag = 2;
+          if (prev >= 0) {
+            cur = prev;  // its row was requested into the second register set
+            pending = 1;
+          } else {
+            cur = -1;
+            state = 0;
+            flag |= 1;
+          }
+        } else {
+          // zero bids went back and forth (exact structural ties, e.g. duplicated columns): the row is left to the
+          // augmenting phase, so that such rows cannot take the sixteen chains out of work one by one
+          waited = 0;
+          cur = -1;
+          state = 0;
+          flag = 1;
+        }
+      }
+    } else if (bidding) {  // a row without a finite entry: nothing to bid for
+      cur = -1;
+      state = 0;
+      flag = 1;
+    } else if (state == 1) {
+      state = 2;  // its row arrives while this pass runs
+    } else {
+      flag = 1;
+    }
+    NIF_ARR_MARK(4);
+    if (lane == 0) flags[wave] = flag;
+    __syncthreads();
+    NIF_ARR_MARK(5);
+    const int f = lane < ARR_W ? flags[lane] : 0;
+    need = (unsigned)__ballot((f & 1) != 0);
+    ++passes;
+    // the tail -- the list handed out and only a few chains left -- is no faster per bid than the Dijkstra steps of
+    // the augmenting kernel, which also ends: hand the last rows over (their col4row is -1)
+    if (next >= total && ARR_W - __popc(need) <= min_chains) break;
+  }
+
+  for (int j = tid; j < n; j += T) {
+    vg[j] = v[j];
+    row4col_g[j] = row4col[j];
+    col4row_g[j] = -1;
+  }
+  __syncthreads();
+  // col4row from row4col; u from v: the matched edge is tight, a free row gets its smallest reduced cost
+  for (int j = tid; j < n; j += T) {
+    const int i = row4col[j];
+    if (i >= 0) {
+      col4row_g[i] = j;
+      u[i] = (double)C[(int64_t)i * ldc + j] - v[j];
+    }
+  }
+  __syncthreads();
+  const int nfree = compact_free();
+  for (int e = wave; e < nfree; e += nw) {
+    const int i = queue[e];
+    const float* __restrict__ crow = C + (int64_t)i * ldc;
+    double b1 = INFINITY;
+    for (int j = lane; j < n; j += 64) b1 = fmin(b1, (double)crow[j] - v[j]);
+    b1 = wave_min_f64(b1 + 0.0);
+    if (lane == 0) u[i] = b1 < INFINITY ? b1 : 0.0;
+  }
+  if (tid == 0) {
+    stats[1] = passes;
+    stats[2] = nfree;
+#ifdef NIF_LAP_ARR_TIMING
+    for (int k = 0; k < 6; ++k) stats[4 + k] = (int)(tacc[k] / (passes > 0 ? passes : 1));
+#endif
+  }
+}
+#undef NIF_ARR_MARK
+
 // Uniqueness certificate for an optimal (col4row, u, v): counts the edges OUTSIDE the matching whose reduced cost
 // c_ij - u_i - v_j is not clearly positive (<= tol_rel * (|c_ij| + |u_i| + |v_j|); a negative one, i.e. infeasible
 // duals, counts too).  Zero such edges means no other assignment reaches the optimal cost, so every exact solver --
@@ -522,6 +816,36 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
   if (init_only) return NIF_OK;
+  if (!scipy_order && n >= 2) {
+    // augmenting row reduction before the shortest-path searches: at most 4 n passes of up to 16 bids each
+    // (NIF_LAP_ARR_PASSES: tuning aid, -1 = skip the phase, k > 0 = that many passes)
+    const int arr_env = env_int("NIF_LAP_ARR_PASSES");
+    const int arr_passes = arr_env < 0 ? 0 : (arr_env > 0 ? arr_env : 4 * n);
+    // measured on unrelated-activation costs (tools/lap_arr_sweep.py, profiles/r3_b_lap_arr_sweep.txt): stop once the
+    // list is handed out and at most 6 chains are left, accept at most 4 zero bids in a row per chain
+    const int arr_min_chains = getenv("NIF_LAP_ARR_MIN_CHAINS") ? env_int("NIF_LAP_ARR_MIN_CHAINS") : 6;
+    const int arr_max_wait = getenv("NIF_LAP_ARR_MAX_WAIT") ? env_int("NIF_LAP_ARR_MAX_WAIT") : 4;
+    if (arr_passes > 0) {
+      const size_t arr_lds = (size_t)n * 16 + (n & 1) * 4 + ARR_W * 16 + 32 * sizeof(int);
+#define NIF_ARR_GO(CPT)                                                                                               \
+  do {                                                                                                                \
+    auto kfn = lap_arr_kernel<CPT>;                                                                                   \
+    if (arr_lds > 48 * 1024)                                                                                          \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)arr_lds);          \
+    hipLaunchKernelGGL(kfn, dim3(1), dim3(1024), arr_lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, arr_passes,    \
+                       arr_min_chains, arr_max_wait);                                                               \
+  } while (0)
+      const int cols = (n + 63) / 64;  // columns a lane holds of its bidder's row
+      if (cols <= 2) NIF_ARR_GO(2);
+      else if (cols <= 4) NIF_ARR_GO(4);
+      else if (cols <= 6) NIF_ARR_GO(6);
+      else if (cols <= 8) NIF_ARR_GO(8);
+      else if (cols <= 12) NIF_ARR_GO(12);
+      else if (cols <= 16) NIF_ARR_GO(16);
+      else NIF_ARR_GO(0);  // two register sets of more than 16 columns spill: these sizes re-read the row from L2
+#undef NIF_ARR_GO
+    }
+  }
 
   // columns per lane: a Dijkstra step is a chain of dependent latencies (cost row -> relax -> wave minima ->
   // mailbox + barrier -> row-of-16 minima); the relax part grows with the columns a lane owns while the

@@ -9,9 +9,15 @@ outputs) are committed.  ``captum`` / ``torchsummary`` are absent from this imag
 and are replaced by empty stub modules (only the ``'uniform'`` importance path,
 which never touches captum, is exercised) -- see SURVEY.md section 8(c).
 
-``fusion_algorithms/otfusion.py`` cannot be imported (``import ot``: POT is not
-installed), so there is no OTFusion golden: OTFusion parity is *unpinned* at the
-``ot.emd`` boundary.
+``fusion_algorithms/otfusion.py`` does ``import ot`` and POT is not installed: OTFusion
+parity is *unpinned* at the ``ot.emd`` boundary (otfusion.py:32).  Everything else of that
+file -- marginals, edge alignment through the previous plan, both ground metrics, the
+barycentric projection, the averaging, the conv / conv-to-linear reshapes -- is pinned by
+``otf.npz``: the reference module is imported with a stand-in ``ot`` module whose ``emd`` is
+an exact solver (scipy: assignment for uniform square problems, HiGHS for the transport
+LP otherwise).  Where the optimal plan is unique that is what POT's network simplex
+returns too; ``otf.<tag>.<mode>.dup<l>_<k>`` marks the problems whose cost matrix has
+duplicated rows or columns (dead units of random-init nets), where it is not.
 
 What is recorded, per fixture (keys are flat strings inside one npz):
   sd{k}.<param>               state_dict of input model k (reference class, seeded init or real ckpt)
@@ -25,6 +31,8 @@ What is recorded, per fixture (keys are flat strings inside one npz):
   kf{M}.fused.<param>
   alf.T.{norm}{init2}, alf.assign.{norm}{init2}   ALFusion._k_means_v2 at level 0
   (alf_kd.npz) head_w, grp.T.{hw}{kd}, kd{A,B,C,D}.fused.<param>   last-level grouping / criteria / KD pass (alf.py:398-454)
+  (otf.npz) <tag>.sd{k}.<param>, <tag>.X, <tag>.<mode>.cost{l}_{k}, .T{l}_{k}, .dup{l}_{k}, <tag>.<mode>.fused.<param>
+                              OTFusion.fuse_models on three fixtures x {acts, wts}; models[:-1] aligned to models[-1]
 """
 import contextlib
 import io
@@ -386,8 +394,110 @@ def fixture_alf_kd():
     return out
 
 
+def _install_ot_stand_in():
+    """`import ot` for the reference's otfusion.py: only ot.emd is used (otfusion.py:32).  Exact optimum of the same
+    transport problem by scipy; returns a tensor like POT's torch backend does (type of the inputs)."""
+    from scipy.optimize import linear_sum_assignment, linprog
+    mod = types.ModuleType('ot')
+
+    def emd(a, b, M, *args, **kwargs):
+        a64, b64 = a.detach().double().numpy(), b.detach().double().numpy()
+        C = M.detach().double().numpy()
+        n0, n1 = C.shape
+        if n0 == n1 and (a64 == a64[0]).all() and (b64 == b64[0]).all():
+            r, c = linear_sum_assignment(C)
+            T = np.zeros_like(C)
+            T[r, c] = a64[0]
+        else:
+            A_eq = np.zeros((n0 + n1, n0 * n1))
+            for i in range(n0):
+                A_eq[i, i * n1:(i + 1) * n1] = 1
+            for j in range(n1):
+                A_eq[n0 + j, j::n1] = 1
+            res = linprog(C.ravel(), A_eq=A_eq[:-1], b_eq=np.concatenate([a64, b64 * (a64.sum() / b64.sum())])[:-1],
+                          bounds=(0, None), method='highs')
+            assert res.status == 0, res.message
+            T = res.x.reshape(n0, n1)
+        return torch.from_numpy(T).to(M.dtype)
+    mod.emd = emd
+    sys.modules['ot'] = mod
+
+
+def run_otf(out, tag, models, X):
+    """OTFusion.fuse_models(models[:-1] -> models[-1]) as run_otf.py:94-110 sets it up, both modes, uniform importances."""
+    _install_ot_stand_in()
+    from fusion_algorithms import otfusion as ref_otf
+    for mode in ('acts', 'wts'):
+        strategy = {'mode': mode, mode: {'activations_dataset': X, 'activation_labels': None,
+                                         'neuron_importance_method': 'uniform', 'normalize_activations': False}}
+        log = []
+        orig = ref_otf.get_ot_matrix
+
+        def recording(cost, mu, nu):
+            T = orig(cost, mu, nu)
+            log.append((cost.detach().cpu().numpy().copy(), T.detach().cpu().numpy().copy()))
+            return T
+        ref_otf.get_ot_matrix = recording
+        copies = [m.copy_model().eval() for m in models]
+        try:
+            fused = quiet(ref_otf.OTFusion(copies[:-1], copies[-1]).fuse_models, strategy,
+                          handle_skip=(mode == 'acts'), handle_bias=True)
+        finally:
+            ref_otf.get_ot_matrix = orig
+        K = len(models) - 1
+        for idx, (C, T) in enumerate(log):
+            l, k = divmod(idx, K)
+            out[f'{tag}.{mode}.cost{l}_{k}'] = C.astype(np.float32)
+            out[f'{tag}.{mode}.T{l}_{k}'] = T.astype(np.float32)
+            dup = len(np.unique(C, axis=0)) < C.shape[0] or len(np.unique(C, axis=1)) < C.shape[1]
+            out[f'{tag}.{mode}.dup{l}_{k}'] = np.array([int(dup)])
+        sd_to(out, f'{tag}.{mode}.fused', fused)
+
+
+def fixture_otf():
+    out = {}
+    # the same three model families as mlp_small / mlp_wide / vgg_tiny (same seeds, so the same weights)
+    models = []
+    for k in range(4):
+        torch.manual_seed(100 + k)
+        models.append(MLPNet(20, 32, 10, use_bias=True, use_activations=False).eval())
+    torch.manual_seed(0)
+    X = torch.randn(48, 1, 4, 5)
+    out['mlp_small.X'] = X.numpy()
+    for k, m in enumerate(models):
+        sd_to(out, f'mlp_small.sd{k}', m)
+    run_otf(out, 'mlp_small', models, X)
+
+    models = []
+    for k in range(3):
+        torch.manual_seed(200 + k)
+        models.append(MLPNet(24, 96, 10, use_bias=True, use_activations=False).eval())
+    torch.manual_seed(1)
+    X = torch.randn(256, 1, 4, 6)
+    out['mlp_wide.X'] = X.numpy()
+    for k, m in enumerate(models):
+        sd_to(out, f'mlp_wide.sd{k}', m)
+    run_otf(out, 'mlp_wide', models, X)
+
+    VGG.cfg['VGG_tiny'] = [8, 'M', 16, 'M', 16, 16, 'M', 32, 32, 'M', 32, 32, 'M']
+    models = []
+    for k in range(3):
+        torch.manual_seed(300 + k)
+        models.append(VGG('VGG_tiny', 10, (3, 32, 32), batch_norm=False, use_bias=True, use_activations=False).eval())
+    torch.manual_seed(2)
+    X = torch.randn(6, 3, 32, 32)
+    out['vgg_tiny.X'] = X.numpy()
+    out['vgg_tiny.cfg'] = np.array([str(c) for c in VGG.cfg['VGG_tiny']])
+    for k, m in enumerate(models):
+        sd_to(out, f'vgg_tiny.sd{k}', m)
+    run_otf(out, 'vgg_tiny', models, X)
+    meta(out)
+    np.savez_compressed(os.path.join(OUT, 'otf.npz'), **out)
+    return out
+
+
 FIXTURES = dict(mlp_small=fixture_mlp_small, mlp_wide=fixture_mlp_wide, vgg_tiny=fixture_vgg_tiny,
-                vit_tiny=fixture_vit_tiny, mlp_real=fixture_mlp_real, alf_kd=fixture_alf_kd)
+                vit_tiny=fixture_vit_tiny, mlp_real=fixture_mlp_real, alf_kd=fixture_alf_kd, otf=fixture_otf)
 
 if __name__ == '__main__':
     for fx in [FIXTURES[n] for n in sys.argv[1:]] or list(FIXTURES.values()):

@@ -54,3 +54,14 @@ def assert_state_close(model, expected, rtol=1e-3, atol=1e-5):
 
 def n_layers(z, tag):
     return len([k for k in z.files if k.startswith(f'{tag}.col')])
+
+
+class SubNpz:
+    """The arrays of one fixture inside a combined npz (keys '<tag>.<rest>'), addressed by '<rest>'."""
+
+    def __init__(self, z, tag):
+        self._z, self._tag = z, tag + '.'
+        self.files = [k[len(self._tag):] for k in z.files if k.startswith(self._tag)]
+
+    def __getitem__(self, key):
+        return self._z[self._tag + key]

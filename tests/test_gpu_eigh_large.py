@@ -257,3 +257,16 @@ def test_c1_kf_fusion_every_layer_refit_checked(ops):
                                                (6400, 4609), (1600, 4609), (1600, 4609), (400, 513)]
     for p in fused.parameters():
         assert bool(torch.isfinite(p).all())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs a second GPU in the process')
+def test_eigh_on_a_second_device_of_the_process(ops):
+    """The > 64 KiB dynamic LDS attribute of the tridiagonalisation / multisection kernels is a per-device property:
+    a second GPU used by the same process (after the first) must get it too (n = 4609 needs 3 * ld * 8 = 110 KiB)."""
+    lam_true, cutoff = _spectra(4609)['lowrank']
+    for dev in (0, 1):
+        with torch.cuda.device(dev):
+            G, Q = _known_spectrum(4609, lam_true, seed=5, device=f'cuda:{dev}')
+            lam, V = ops.eigh_kept(G, cutoff)
+            assert lam.shape[0] == 4609 // 3
+            assert float((G @ V - V * lam).abs().max()) <= 2e-14 * float(G.abs().max()) * 4609

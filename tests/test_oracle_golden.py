@@ -7,7 +7,7 @@ from oracle import alf as o_alf
 from oracle import git_rebasin as o_gr
 from oracle import hf_kf as o_hf
 from oracle import otfusion as o_otf
-from tests.helpers import load_npz, build_models, fused_state, assert_state_close, n_layers
+from tests.helpers import load_npz, build_models, fused_state, assert_state_close, n_layers, SubNpz
 
 FIXTURES = ['mlp_small', 'mlp_wide', 'vgg_tiny', 'mlp_real']
 
@@ -148,3 +148,25 @@ def test_alf_head_criterion_oracle_matches_torch_modules():
     assert torch.allclose(o_alf.head_criterion(True, None, True, w)(p, t), torch.nn.MSELoss()(p, t))
     assert torch.allclose(o_alf.head_criterion(True, hw, True, w)(p, t), torch.nn.KLDivLoss(reduction='batchmean')(p, t))
     assert torch.allclose(o_alf.head_criterion(True, hw, False, w)(p, t), ((p - t) ** 2 * w).mean())
+
+
+@pytest.mark.parametrize('name', ['mlp_small', 'mlp_wide', 'vgg_tiny'])
+@pytest.mark.parametrize('mode', ['acts', 'wts'])
+def test_otf_oracle_against_the_reference_run_with_a_stand_in_exact_solver(name, mode):
+    """otfusion.py:193-361 minus ot.emd: the reference module itself was run (make_golden.py otf) with `ot.emd` replaced
+    by an exact scipy solve; the oracle restatement must give the same ground metrics, the same plans (no cost matrix
+    of these fixtures has duplicated rows / columns, so the optimal vertex is unique) and the same fused weights.
+    Parity stays unpinned at ot.emd itself (POT absent)."""
+    z = SubNpz(load_npz('otf'), name)
+    models, X = build_models(name, z)
+    log = []
+    fused = o_otf.otf_fuse(models[:-1], models[-1], X, mode=mode, log=log)
+    assert len(log) == len([k for k in z.files if k.startswith(f'{mode}.cost')])
+    for rec in log:
+        l, k = rec['layer'], rec['model']
+        assert int(z[f'{mode}.dup{l}_{k}'][0]) == 0
+        np.testing.assert_allclose(rec['cost'], z[f'{mode}.cost{l}_{k}'], rtol=1e-5, atol=1e-6)
+        Tg = z[f'{mode}.T{l}_{k}']
+        assert (rec['T'].argmax(1) == Tg.argmax(1)).all(), (l, k)
+        np.testing.assert_allclose(rec['T'], Tg, rtol=1e-6, atol=1e-9)
+    assert_state_close(fused, fused_state(z, mode), rtol=1e-5)
