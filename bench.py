@@ -3,6 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W            (default workload: C2 level throughput)
   python bench.py --workload c1|c3|c4 [--steps K]           (end-to-end fusion wall-clock, one GPU: bench_e2e.py)
+  python bench.py --workload c5 --gpus N [--c5-width 768|3072] (config 5: 8-model clustering level, rows sharded over N ranks)
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (BASELINE.json configs[1], SURVEY section 8d "C2"): one OTFusion activation-mode
@@ -171,7 +172,9 @@ def main():
         faulthandler.dump_traceback_later(int(watchdog), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--workload', choices=['c2', 'c1', 'c3', 'c4', 'sk'], default='c2',
+    ap.add_argument('--c5-width', type=int, default=3072, help='--workload c5: width per model (768 or 3072; N = 8 x width)')
+    ap.add_argument('--c5-rows', type=int, default=200_000, help='--workload c5: fusion samples in all (sharded over the ranks)')
+    ap.add_argument('--workload', choices=['c2', 'c1', 'c3', 'c4', 'c5', 'sk'], default='c2',
                     help='c2 (default): the per-level throughput benchmark; c1 / c3 / c4: end-to-end fusion wall-clock of '
                          'BASELINE.json configs 1 / 3 / 4 on one GPU; sk: the additional Sinkhorn mode (bench_e2e.py)')
     ap.add_argument('--steps', type=int, default=None, help='timed steps (default 2000 levels; 5 fusions / solves for c1/c3/c4/sk)')
@@ -214,6 +217,26 @@ def main():
             dist.init_process_group(args.backend)
     from neuron_interpolation_model_fusion_amd import ops
 
+    if args.workload == 'c5':
+        # BASELINE.json config 5 (8 models at ViT-B width, 200 k samples sharded over the node): runs on N ranks
+        import bench_e2e
+        steps = 5 if args.steps is None else args.steps
+        warmup = 1 if args.warmup is None else args.warmup
+        r = bench_e2e.run_c5(ops, device, steps, warmup, dist=dist, world=world, rank=rank, width=args.c5_width,
+                             rows=args.c5_rows, host_sync=(world > 1 and args.backend != 'nccl'))
+        if rank == 0:
+            print(json.dumps({
+                'metric': 'fused levels/sec', 'value': r['steps'] / r['elapsed'], 'unit': 'levels/s', 'n_gpus': world,
+                'steps': steps, 'warmup': max(warmup, 1), 'ms_per_step': r['elapsed'] / r['steps'] * 1e3,
+                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': dict(workload=r['workload'], rows_per_gpu=r['m_local'],
+                               parallelism=f'rows sharded over {world} GPU(s), one f64 all-reduce of the packed upper '
+                                           f'triangle per level' if dist is not None else 'single GPU', **r['extra']),
+                'roofline': r['roofline']}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload != 'c2':
         if world != 1:
             raise SystemExit('--workload c1/c3/c4 are single-GPU end-to-end runs (use the default workload for N > 1)')

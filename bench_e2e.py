@@ -208,6 +208,85 @@ def run_sk(ops, device, steps, warmup, n=8192, iters=200):
                           'K build, the plan and the host round trips every 50 iterations are inside'})
 
 
+def run_c5(ops, device, steps, warmup, dist=None, world=1, rank=0, width=3072, models=8, rows=200_000, lloyd_iters=3,
+           host_sync=False):
+    """BASELINE.json config 5: synthetic 8-model fusion at ViT-B width -- one level of neuron clustering on N = 8 * width
+    neuron columns over 200 000 fusion samples whose ROWS are sharded over the ranks (strong scaling: rows per GPU =
+    rows / world).  One step = this rank's partial symmetric Gram (f32 MFMA) -> ONE all-reduce of the packed block upper
+    triangle in f64 (written by the reduction kernel, expanded by one kernel into the f32 k-means storage + f64
+    diagonal; skipped with one rank) -> ALF's first assignment + `lloyd_iters` Lloyd steps on the replicated N x N Gram
+    (alf.py:221-272).  Returns the dict bench.py prints; time is the max over ranks."""
+    import contextlib as _ctx
+    from neuron_interpolation_model_fusion_amd import parallel
+    N, k = models * width, width
+    lo, hi = rows * rank // world, rows * (rank + 1) // world
+    m_local = hi - lo
+    g = torch.Generator(device=device).manual_seed(500 + rank)
+    A = torch.empty((m_local, N), dtype=torch.float32, device=device)
+    perms = [torch.randperm(width, generator=torch.Generator().manual_seed(77 + j)).to(device) for j in range(models)]
+    for r0 in range(0, m_local, 8192):   # model j = a noisy column permutation of a shared signal, chunked to bound temporaries
+        r1 = min(m_local, r0 + 8192)
+        base = torch.randn(r1 - r0, width, device=device, generator=g)
+        for j in range(models):
+            A[r0:r1, j * width:(j + 1) * width] = 0.9 * base[:, perms[j]] + 0.3 * torch.randn(r1 - r0, width, device=device, generator=g)
+    s = torch.ones(N, device=device)
+    sharded = dist is not None and world > 1
+    state = {}
+
+    def level():
+        ctx = parallel.SampleSharding(None) if sharded else _ctx.nullcontext()
+        with ctx:
+            if sharded and host_sync:
+                torch.cuda.synchronize()   # gloo rehearsal on a shared GPU only (see bench.py level_front)
+            G, gdiag = ops.kmeans_gram(A, rows_sharded=True)
+        km = ops.KMeans(G, gdiag, s, k, gdiag=gdiag)
+        assign = km.assign_to_neurons(0)
+        for _ in range(lloyd_iters):
+            assign, nearest, cost, kprime = km.lloyd_step(assign)
+        state['assign'], state['cost'], state['kprime'] = assign, cost, kprime
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(warmup, 1)):
+        level()
+    sync()
+    ops.profile_collect(ops.PROF_XTY)
+    ops.profile_enable(True, slots=[ops.PROF_XTY])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        level()
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.profile_enable(False)
+    xty_ms, launches = ops.profile_collect(ops.PROF_XTY)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # every model's neuron j' = perms[j]^-1 ... lands in the cluster of the model-0 neuron it copies: clusters of `models`
+    assign = state['assign'].view(models, width)
+    want = torch.stack([torch.argsort(perms[0])[perms[j]] for j in range(models)])   # cluster label = model-0 column of the same signal
+    planted = bool((assign.long() == want).all())
+    flops = float(m_local) * N * (N + 1)
+    achieved = flops * launches / (xty_ms * 1e-3) / 1e12 if xty_ms > 0 else None
+    return dict(
+        elapsed=elapsed, steps=steps, m_local=m_local, N=N, k=k,
+        workload=f'C5 synthetic {models}-model fusion at width {width}: N = {N} neuron columns, k = {k} clusters, {rows} '
+                 f'fusion samples with rows sharded over {world} GPU(s) ({m_local} per GPU); per level: partial symmetric '
+                 f'Gram (f32 MFMA) + one f64 all-reduce of the packed block upper triangle + first assignment + '
+                 f'{lloyd_iters} Lloyd steps on the replicated Gram',
+        extra={'planted_clusters_recovered': planted, 'kprime': int(state['kprime']), 'lloyd_cost': float(state['cost']),
+               'allreduce_bytes_per_level': 8 * (ops.lib.nif_packed_upper_len(N, parallel.TRI_BLOCK)) if sharded else 0},
+        roofline={'kernel': 'nif::xty_kernel<float, MmaF32> symmetric Gram (v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
+                  'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                  'frac': achieved / F32_MFMA_PEAK_TFLOPS if achieved else None, 'traffic': None,
+                  'algorithmic_flops_per_launch': flops, 'avg_kernel_ms': xty_ms / max(launches, 1), 'launches': launches,
+                  'share_of_wall_clock': xty_ms * 1e-3 / elapsed if elapsed > 0 else None})
+
+
 RUNNERS = {'c1': run_c1, 'c3': run_c3, 'c4': run_c4, 'sk': run_sk}
 
 

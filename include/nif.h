@@ -111,6 +111,21 @@ int nif_xty(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, i
 int nif_xty_sym_gf32(const void* A, int64_t lda, int64_t m, int n, int in_dtype, int acc, int flags, float* G,
                      int64_t ldg, double* gdiag, void* ws, size_t ws_bytes, void* stream);
 
+/* Sample-sharded runs (one process per GPU, rows split over the ranks; no counterpart in the reference, which is
+ * single-process) sum the ranks' partial symmetric Grams -- k-means Gram alf.py:227-276 / hf_kf.py:429-456, normal
+ * equations hf_kf.py:213,377 -- with ONE all-reduce of the block upper triangle: block rows of `block` rows, block row
+ * b (first row i0 = b * block) keeps columns i0 .. n-1, row-major, block rows back to back (nif_packed_upper_len
+ * doubles in all; about n^2 / 2 for n >> block).  nif_xty_sym_packed writes a rank's partial A^T A in that layout
+ * straight from the split-K reduction (na, optional: the squared column norms, e.g. the tail of the same buffer);
+ * nif_unpack_upper expands the reduced buffer to the full symmetric matrix, f64 or the f32 k-means storage
+ * (out_dtype NIF_F32 / NIF_F64; gdiag optional: the unrounded diagonal).  Same values, entry for entry, as reducing
+ * the full matrices.  Workspace as nif_xty_workspace_bytes(m, n, n, acc, flags | NIF_SYMMETRIC).  n <= 65535. */
+size_t nif_packed_upper_len(int n, int block);
+int nif_xty_sym_packed(const void* A, int64_t lda, int64_t m, int n, int in_dtype, int acc, int flags, int block,
+                       double* packed, double* na, void* ws, size_t ws_bytes, void* stream);
+int nif_unpack_upper(const double* packed, int n, int block, void* G, int64_t ldg, int out_dtype, double* gdiag,
+                     void* stream);
+
 /* ---------------------------------------------------------------------------
  * Cost-matrix epilogues: O(1) work per (i, j) on top of the Gram quantities.
  * C is n0 x n1 f32 (ldc), the layout scipy.optimize.linear_sum_assignment /
@@ -188,6 +203,17 @@ int nif_lap_solve_f32_static(const float* C, int64_t ldc, int n, int flags, int3
  * optimal assignment is unique, so scipy returns the same one whatever its tie rule. */
 int nif_lap_count_tight_f32(const float* C, int64_t ldc, int n, const int32_t* col4row, const double* u, const double* v,
                             double tol_rel, int32_t* count, void* stream);
+/* The same question answered without demanding strict slackness: *result (device int) = 0 when the graph of near-tight
+ * edges outside the matching (reduced cost <= tol_rel * (|c| + |u| + |v|)) contains no alternating cycle, the matched
+ * edges are tight and the duals feasible -- then no other assignment reaches the optimal cost, however many ties the
+ * solver's own dual updates left behind (they do, by construction: the bidder's best and second-best columns tie);
+ * non-zero otherwise.  ws from nif_lap_certify_workspace_bytes(n).  No counterpart in the reference: it is what lets
+ * the call sites of scipy's linear_sum_assignment (hf_kf.py:251, git_rebasin.py:112, alf.py:138) take the fast solver's
+ * answer wherever the optimum is unique. */
+size_t nif_lap_certify_workspace_bytes(int n);
+int nif_lap_certify_unique_f32(const float* C, int64_t ldc, int n, const int32_t* col4row, const int32_t* row4col,
+                               const double* u, const double* v, double tol_rel, int32_t* result, void* ws,
+                               size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * nif_refit_gather: weight write-back under a matching,

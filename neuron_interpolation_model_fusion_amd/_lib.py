@@ -44,6 +44,9 @@ SIGNATURES = {
     'nif_xty_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32]),
     'nif_xty': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     'nif_xty_sym_gf32': (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    'nif_packed_upper_len': (_sz, [_i32, _i32]),
+    'nif_xty_sym_packed': (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'nif_unpack_upper': (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp]),
     'nif_cost_dist': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'nif_cost_hf': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     'nif_lap_workspace_bytes': (_sz, [_i32]),
@@ -79,6 +82,8 @@ SIGNATURES = {
     'nif_wmse_forward': (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _sz, _vp]),
     'nif_wmse_backward': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     'nif_lap_count_tight_f32': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _c.c_double, _vp, _vp]),
+    'nif_lap_certify_workspace_bytes': (_sz, [_i32]),
+    'nif_lap_certify_unique_f32': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _c.c_double, _vp, _vp, _sz, _vp]),
     'nif_im2row_f32': (_i32, [_vp, _i64] + [_i32] * 10 + [_vp, _i64, _vp]),
     'nif_lsq_refit_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
     'nif_lsq_refit_f32': (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp,

@@ -678,6 +678,100 @@ __global__ void lap_count_tight_kernel(const float* __restrict__ C, int64_t ldc,
   if (lane == 0 && bad) atomicAdd(count, bad);
 }
 
+// ---- uniqueness certificate that tolerates ties: no alternating cycle through near-tight edges --------------------
+// lap_count_tight_kernel's test (NO near-tight edge outside the matching) is sufficient but far from necessary: the
+// augmenting row reduction and the shortest-path dual updates leave tight edges behind by construction (a bidder's
+// best and second-best columns tie), and the optimum is unique all the same unless such edges close a cycle.  Another
+// optimal assignment differs from this one by alternating cycles, i.e. by a directed cycle in the graph on the rows
+// with an arc i -> row4col[j] for every near-tight edge (i, j) outside the matching; if that graph is acyclic, every
+// alternating cycle contains an edge whose reduced cost exceeds the margin, and every other assignment costs more.
+// Pass 1 (all CUs): collect the arcs (reduced cost <= tol_rel * (|c| + |u| + |v|)) and count what voids a certificate
+// outright (a matched edge that is not tight, a clearly negative reduced cost, an unmatched row).  Pass 2 (one
+// workgroup): peel rows without outgoing arcs until nothing changes; rows left over sit on or lead into a cycle.
+__global__ void lap_cert_arcs_kernel(const float* __restrict__ C, int64_t ldc, int n, const int* __restrict__ col4row,
+                                     const int* __restrict__ row4col, const double* __restrict__ u,
+                                     const double* __restrict__ v, double tol_rel, int* __restrict__ ctl,
+                                     int2* __restrict__ arcs, int cap) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* row = C + (int64_t)i * ldc;
+  const double ui = u[i];
+  const int mate = col4row[i];
+  int bad = mate < 0 || mate >= n ? (lane == 0) : 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    bool arc = false;
+    if (j < n) {
+      const double c = (double)row[j], vj = v[j];
+      const double rc = c - ui - vj;
+      const double tol = tol_rel * (fabs(c) + fabs(ui) + fabs(vj));
+      if (j == mate) {
+        if (fabs(rc) > 1e-5 * tol) ++bad;
+      } else if (!(rc > -tol)) {
+        ++bad;  // infeasible duals (or NaN)
+      } else if (!(rc > tol)) {
+        arc = true;
+      }
+    }
+    const unsigned long long m = __ballot(arc);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&ctl[1], __popcll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (arc) {
+        const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (at < cap) arcs[at] = make_int2(i, row4col[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if (lane == 0 && bad) atomicAdd(&ctl[0], bad);
+}
+
+// ctl[0] = disqualifying edges, ctl[1] = arcs found; result -> ctl[2]: 0 = unique optimum certified, else not
+__global__ __launch_bounds__(1024) void lap_cert_acyclic_kernel(int n, int* __restrict__ ctl, const int2* __restrict__ arcs,
+                                                                int cap) {
+  extern __shared__ int cert_sm[];
+  int* outdeg = cert_sm;       // arcs still leaving row i; -1 once the row is peeled
+  int* changed = cert_sm + n;  // [2]: flag per parity
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int narcs = ctl[1];
+  if (ctl[0] != 0 || narcs > cap) {  // uniform
+    if (tid == 0) ctl[2] = 1;
+    return;
+  }
+  for (int i = tid; i < n; i += T) outdeg[i] = 0;
+  if (tid < 2) changed[tid] = 0;
+  __syncthreads();
+  for (int e = tid; e < narcs; e += T) atomicAdd(&outdeg[arcs[e].x], 1);
+  __syncthreads();
+  // a row with no outgoing arc cannot be on a cycle: peel it, which removes the arcs that point to it
+  for (int round = 0; round <= n; ++round) {
+    int* flag = changed + (round & 1);
+    for (int i = tid; i < n; i += T)
+      if (outdeg[i] == 0) {
+        outdeg[i] = -2;  // peeled in this round
+        *flag = 1;
+      }
+    __syncthreads();
+    if (*flag == 0) break;  // uniform
+    for (int e = tid; e < narcs; e += T) {
+      const int2 a = arcs[e];
+      if (outdeg[a.y] == -2 && outdeg[a.x] > 0) atomicSub(&outdeg[a.x], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += T)
+      if (outdeg[i] == -2) outdeg[i] = -1;
+    if (tid == 0) changed[(round + 1) & 1] = 0;
+    __syncthreads();
+  }
+  int left = 0;
+  for (int i = tid; i < n; i += T) left |= outdeg[i] > 0;
+  if (left) ctl[2] = 1;  // any number of threads may store the same value
+}
+
 struct LapWs {
   size_t off_part, off_u, off_v, off_jbest, off_claim, off_r4c, total;
   int chunks, rows_per_chunk;
@@ -893,5 +987,32 @@ extern "C" int nif_lap_count_tight_f32(const float* C, int64_t ldc, int n, const
   clear_err();
   if (hipMemsetAsync(count, 0, sizeof(int32_t), st) != hipSuccess) return NIF_ERR_LAUNCH;
   hipLaunchKernelGGL(lap_count_tight_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, ldc, n, col4row, u, v, tol_rel, count);
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+}
+
+extern "C" size_t nif_lap_certify_workspace_bytes(int n) {
+  if (n <= 0 || n > NIF_LAP_MAX_N) return 0;
+  return 256 + (size_t)8 * n * sizeof(int2);
+}
+
+extern "C" int nif_lap_certify_unique_f32(const float* C, int64_t ldc, int n, const int32_t* col4row, const int32_t* row4col,
+                                          const double* u, const double* v, double tol_rel, int32_t* result, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_lap_certify_unique_f32");
+  using namespace nif;
+  if (!C || !col4row || !row4col || !u || !v || !result || n <= 0 || ldc < n || !(tol_rel >= 0.0)) return NIF_ERR_INVALID_ARG;
+  if (n > NIF_LAP_MAX_N) return NIF_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < nif_lap_certify_workspace_bytes(n)) return NIF_ERR_WORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  clear_err();
+  int* ctl = reinterpret_cast<int*>(ws);
+  int2* arcs = reinterpret_cast<int2*>(reinterpret_cast<unsigned char*>(ws) + 256);
+  const int cap = 8 * n;
+  if (hipMemsetAsync(ctl, 0, 256, st) != hipSuccess) return NIF_ERR_LAUNCH;
+  hipLaunchKernelGGL(lap_cert_arcs_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, ldc, n, col4row, row4col, u, v, tol_rel,
+                     ctl, arcs, cap);
+  const size_t lds = (size_t)(n + 2) * sizeof(int);
+  hipLaunchKernelGGL(lap_cert_acyclic_kernel, dim3(1), dim3(1024), lds, st, n, ctl, arcs, cap);
+  if (hipMemcpyAsync(result, ctl + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) return NIF_ERR_LAUNCH;
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }

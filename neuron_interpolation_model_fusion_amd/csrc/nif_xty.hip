@@ -857,6 +857,55 @@ __global__ __launch_bounds__(256) void xty_reduce_sym_kernel(const acc_t* __rest
   }
 }
 
+// ---- packed block upper triangle: what a sample-sharded run sends through its all-reduce ----------------------------
+// Rows are grouped in block rows of `block` rows; block row b (first row i0 = b * block) keeps its columns from i0 on,
+// row-major with row length n - i0, block rows back to back: the diagonal blocks in full, nothing left of them --
+// about half of the n^2 entries for n >> block.  The partial Grams of the ranks are summed in this layout and mirrored
+// afterwards (xty_unpack_upper_kernel): entry for entry the result of reducing the full matrix.
+__host__ __device__ __forceinline__ int64_t packed_upper_offset(int i, int j, int n, int block) {
+  const int64_t b = i / block, i0 = b * block;
+  const int64_t base = (int64_t)block * (b * (int64_t)n - (int64_t)block * (b * (b - 1) / 2));
+  return base + (int64_t)(i - i0) * (n - i0) + (j - i0);
+}
+
+// split-K reduction of a symmetric Gram straight into the packed layout (same chains per entry as xty_reduce_kernel)
+template <typename acc_t>
+__global__ void xty_reduce_packed_kernel(const acc_t* __restrict__ slab, int splits, int n, int np, int block,
+                                         double* __restrict__ packed) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= n || i > j) return;
+  const acc_t* s = slab + (int64_t)i * np + j;
+  const int64_t stride = (int64_t)np * np;
+  double c[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int k = 0;
+  for (; k + 7 < splits; k += 8) {
+    acc_t t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = s[(k + q) * stride];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] += (double)t[q];
+  }
+  for (; k < splits; ++k) c[0] += (double)s[k * stride];
+  const double g = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+  packed[packed_upper_offset(i, j, n, block)] = g;
+  if (i != j && j / block == i / block) packed[packed_upper_offset(j, i, n, block)] = g;  // inside a diagonal block
+}
+
+// G (n x n, f64 or f32 storage) from the packed layout; gdiag (optional): the diagonal in f64
+template <typename OT>
+__global__ void xty_unpack_upper_kernel(const double* __restrict__ packed, int n, int block, OT* __restrict__ G,
+                                        int64_t ldg, double* __restrict__ gdiag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= n) return;
+  const int i0 = i / block * block;
+  // left of the block row's first column the entry lives in the block row of j, transposed
+  const double g = j >= i0 ? packed[packed_upper_offset(i, j, n, block)] : packed[packed_upper_offset(j, i, n, block)];
+  G[(int64_t)i * ldg + j] = (OT)g;
+  if (gdiag && i == j) gdiag[i] = g;
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 
 struct XtyPlan {
@@ -1013,9 +1062,11 @@ namespace nif {
 template <typename OT>
 static int xty_impl(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t m, int n0, int n1, int in_dtype,
                     int acc, int flags, OT* G, int64_t ldg, double* gdiag, double* na, double* nb, void* ws,
-                    size_t ws_bytes, void* stream) {
+                    size_t ws_bytes, void* stream, int pack_block = 0) {
   // m == 0 (an empty shard): the operand pointers are never dereferenced and may be null
-  if ((m > 0 && (!A || !B)) || !G || m < 0 || n0 <= 0 || n1 <= 0 || ldg < n1) return NIF_ERR_INVALID_ARG;
+  // pack_block > 0 (symmetric, OT = double): G is the packed block-upper-triangle buffer, ldg is not used
+  if ((m > 0 && (!A || !B)) || !G || m < 0 || n0 <= 0 || n1 <= 0 || (pack_block <= 0 && ldg < n1)) return NIF_ERR_INVALID_ARG;
+  if (pack_block > 0 && (!(flags & NIF_SYMMETRIC) || sizeof(OT) != 8 || gdiag)) return NIF_ERR_INVALID_ARG;
   if (in_dtype != NIF_F32 && in_dtype != NIF_F64) return NIF_ERR_INVALID_ARG;
   if (acc != NIF_F32 && acc != NIF_F64) return NIF_ERR_INVALID_ARG;
   if (in_dtype == NIF_F64 && acc != NIF_F64) return NIF_ERR_INVALID_ARG;
@@ -1074,9 +1125,19 @@ static int xty_impl(const void* A, int64_t lda, const void* B, int64_t ldb, int6
   const int nmax = n0 > n1 ? n0 : n1;
   dim3 rg((nmax + 255) / 256, n0 + 2);
   const int nt64 = (n0 + 63) / 64;
-  const bool sym_tiles = sym && nt64 >= 45;  // >= 1000 upper tiles: enough workgroups to fill the chip
+  const bool sym_tiles = sym && nt64 >= 45 && pack_block <= 0;  // >= 1000 upper tiles: enough workgroups to fill the chip
   int ybase = 0;
-  if (sym_tiles) {
+  if (pack_block > 0) {
+    double* packed = reinterpret_cast<double*>(G);
+    if (acc == NIF_F32)
+      hipLaunchKernelGGL((xty_reduce_packed_kernel<float>), dim3((n0 + 255) / 256, n0), dim3(256), 0, st,
+                         (const float*)a.slab, pl.splits, n0, pl.n0p, pack_block, packed);
+    else
+      hipLaunchKernelGGL((xty_reduce_packed_kernel<double>), dim3((n0 + 255) / 256, n0), dim3(256), 0, st,
+                         (const double*)a.slab, pl.splits, n0, pl.n0p, pack_block, packed);
+    ybase = n0;
+    rg = dim3((nmax + 255) / 256, 2);
+  } else if (sym_tiles) {
     if (acc == NIF_F32)
       hipLaunchKernelGGL((xty_reduce_sym_kernel<float, OT>), dim3(nt64, nt64), dim3(256), 0, st, (const float*)a.slab,
                          pl.splits, n0, pl.n0p, G, ldg, gdiag);
@@ -1086,7 +1147,7 @@ static int xty_impl(const void* A, int64_t lda, const void* B, int64_t ldb, int6
     ybase = n0;  // the norm rows, if asked for, through the general kernel
     rg = dim3((nmax + 255) / 256, 2);
   }
-  if (!sym_tiles || na || nb) {
+  if ((!sym_tiles && pack_block <= 0) || na || nb) {
     if (acc == NIF_F32) {
       hipLaunchKernelGGL((xty_reduce_kernel<float, OT>), rg, dim3(256), 0, st, (const float*)a.slab,
                          (const float*)a.nslab_a, (const float*)a.nslab_b, pl.splits, n0, n1, pl.n0p, pl.n1p, pl.tm, sym,
@@ -1116,4 +1177,35 @@ extern "C" int nif_xty_sym_gf32(const void* A, int64_t lda, int64_t m, int n, in
   if (!gdiag) return NIF_ERR_INVALID_ARG;
   return nif::xty_impl<float>(A, lda, A, lda, m, n, n, in_dtype, acc, flags | NIF_SYMMETRIC, G, ldg, gdiag, nullptr, nullptr,
                               ws, ws_bytes, stream);
+}
+
+extern "C" size_t nif_packed_upper_len(int n, int block) {
+  if (n <= 0 || block <= 0) return 0;
+  const int last = (n - 1) / block * block;  // first row of the last block row
+  return (size_t)nif::packed_upper_offset(last, last, n, block) + (size_t)(n - last) * (size_t)(n - last);
+}
+
+extern "C" int nif_xty_sym_packed(const void* A, int64_t lda, int64_t m, int n, int in_dtype, int acc, int flags, int block,
+                                  double* packed, double* na, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_xty_sym_packed");
+  if (block <= 0 || !packed) return NIF_ERR_INVALID_ARG;
+  return nif::xty_impl<double>(A, lda, A, lda, m, n, n, in_dtype, acc, flags | NIF_SYMMETRIC, packed, n, nullptr, na, nullptr,
+                               ws, ws_bytes, stream, block);
+}
+
+extern "C" int nif_unpack_upper(const double* packed, int n, int block, void* G, int64_t ldg, int out_dtype, double* gdiag,
+                                void* stream) {
+  nif::Range nif_range_("nif_unpack_upper");
+  using namespace nif;
+  if (!packed || !G || n <= 0 || block <= 0 || ldg < n || (out_dtype != NIF_F32 && out_dtype != NIF_F64))
+    return NIF_ERR_INVALID_ARG;
+  if (n > 65535) return NIF_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  clear_err();
+  const dim3 grid((n + 255) / 256, n);
+  if (out_dtype == NIF_F64)
+    hipLaunchKernelGGL(xty_unpack_upper_kernel<double>, grid, dim3(256), 0, st, packed, n, block, (double*)G, ldg, gdiag);
+  else
+    hipLaunchKernelGGL(xty_unpack_upper_kernel<float>, grid, dim3(256), 0, st, packed, n, block, (float*)G, ldg, gdiag);
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }

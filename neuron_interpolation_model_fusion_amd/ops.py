@@ -75,6 +75,15 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
     flags = ((_lib.NIF_RELU_A if relu_a else 0) | (_lib.NIF_RELU_B if relu_b else 0) |
              (_lib.NIF_SYMMETRIC if symmetric else 0) | (_lib.NIF_TRANS_A if trans_a else 0) |
              (_lib.NIF_TRANS_B if trans_b else 0) | (_lib.NIF_XTY_SPLIT_BF16 if split_bf16 else 0))
+    if rows_sharded and symmetric and out is None:
+        from . import parallel
+        if parallel.SampleSharding.wants_packed(n0):
+            # one collective of the block upper triangle, written by the reduction kernel and expanded by one kernel
+            buf, plen = xty_sym_packed(A, acc=acc, relu=relu_a, trans=trans_a, norms=norms)
+            parallel.all_reduce_sum(buf, parallel.SampleSharding._active.group)
+            G = unpack_upper(buf, n0)
+            na = buf[plen:plen + n0] if norms else None
+            return G, na, na
     with torch.cuda.device(A.device):
         if out is not None:
             G, na, nb = out
@@ -107,6 +116,48 @@ def xty(A, B=None, *, acc='f32', relu_a=False, relu_b=False, trans_a=False, tran
     return G, na, nb
 
 
+def xty_sym_packed(A, *, acc='f32', relu=False, trans=False, norms=False, block=None, tail=0):
+    """This rank's partial A^T A as the packed block upper triangle (parallel.pack_gram_upper's layout), written by
+    the split-K reduction itself -- no full matrix, no packing copies.  Returns (buf, plen): one f64 buffer
+    [packed | na (n, with norms=True) | `tail` spare entries] ready for the all-reduce, and the length of the packed
+    part.  unpack_upper() expands the reduced buffer."""
+    from . import parallel
+    A = _mat(A, 'A')
+    _need_gpu(A)
+    if A.dtype not in _DT:
+        raise TypeError(f'xty_sym_packed needs float32/float64 input, got {A.dtype}')
+    block = int(block or parallel.TRI_BLOCK)
+    m = A.shape[1] if trans else A.shape[0]
+    n = A.shape[0] if trans else A.shape[1]
+    accv = _lib.NIF_F64 if (acc == 'f64' or A.dtype == torch.float64) else _lib.NIF_F32
+    flags = (_lib.NIF_RELU_A | _lib.NIF_RELU_B if relu else 0) | _lib.NIF_SYMMETRIC | \
+        (_lib.NIF_TRANS_A | _lib.NIF_TRANS_B if trans else 0)
+    plen = lib.nif_packed_upper_len(n, block)
+    with torch.cuda.device(A.device):
+        buf = torch.empty(plen + (n if norms else 0) + tail, dtype=torch.float64, device=A.device)
+        na = buf[plen:plen + n] if norms else None
+        nbytes = lib.nif_xty_workspace_bytes(m, n, n, accv, flags)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=A.device)
+        check(lib.nif_xty_sym_packed(_ptr(A), _ld(A), m, n, _DT[A.dtype], accv, flags, block, _ptr(buf), _ptr(na), _ptr(ws),
+                                     nbytes, _stream()), 'nif_xty_sym_packed')
+    return buf, plen
+
+
+def unpack_upper(buf, n, *, block=None, dtype=torch.float64, gdiag=False):
+    """The full symmetric n x n matrix from a (reduced) packed block upper triangle, as f64 or as the f32 k-means
+    storage; gdiag=True also returns the unrounded f64 diagonal."""
+    from . import parallel
+    _need_gpu(buf)
+    block = int(block or parallel.TRI_BLOCK)
+    if buf.dtype != torch.float64 or not buf.is_contiguous() or buf.numel() < lib.nif_packed_upper_len(n, block):
+        raise ValueError('unpack_upper: a contiguous float64 buffer of at least nif_packed_upper_len(n, block) entries')
+    with torch.cuda.device(buf.device):
+        G = torch.empty((n, n), dtype=dtype, device=buf.device)
+        gd = torch.empty(n, dtype=torch.float64, device=buf.device) if gdiag else None
+        check(lib.nif_unpack_upper(_ptr(buf), n, block, _ptr(G), n, _DT[dtype], _ptr(gd), _stream()), 'nif_unpack_upper')
+    return (G, gd) if gdiag else G
+
+
 def cost_dist(G, na, nb, s0=None, s1=None, colscale=None):
     """C = scale * sqrt(max(na_i + nb_j - 2 G_ij, 0)) as f32 (see nif_cost_dist)."""
     _need_gpu(G, na, nb, s0, s1, colscale)
@@ -136,6 +187,21 @@ def cost_hf(G01, pp0, pp1, r0, r1, s0, s1):
 LAP_CERT_TOL = 1e-9  # relative reduced-cost margin below which a non-matching edge counts as a possible tie
 
 
+def _has_duplicate_lines(C):
+    """0-d bool tensor: C has two identical rows or two identical columns (what dead units of a random-initialised
+    network produce: exact structural ties, hence an ambiguous optimum).  Compared through (sum, 2-norm) of every line
+    in f64: identical lines give identical bits, and distinct lines that agree in both do not happen by accident."""
+    found = None
+    for dim in (0, 1):
+        s1 = C.sum(dim, dtype=torch.float64)
+        s2 = torch.linalg.vector_norm(C, ord=2, dim=dim, dtype=torch.float64)
+        idx = torch.argsort(s1)
+        a, b = s1[idx], s2[idx]
+        d = ((a[1:] == a[:-1]) & (b[1:] == b[:-1])).any()
+        found = d if found is None else (found | d)
+    return found
+
+
 def lap_solve(C, duals=False, scipy_order=False):
     """Min-cost perfect matching of a square f32 cost matrix on the device.
 
@@ -144,7 +210,8 @@ def lap_solve(C, duals=False, scipy_order=False):
     scipy_order=True: the matching scipy.optimize.linear_sum_assignment returns, also when the optimum is not unique
     because of exact structural ties.  Where the parallel dual initialisation already matches most rows (trained or
     planted models) the fast solver finishes the problem and a certificate pass checks that no edge outside the
-    matching is tight (``nif_lap_count_tight_f32``): the optimum is then unique and scipy's answer is this one.
+    matching closes an alternating cycle of near-tight edges (``nif_lap_certify_unique_f32``): the optimum is then unique and
+    scipy's answer is this one.
     Otherwise -- random-initialised networks with dead units are ambiguous almost everywhere -- the kernel that
     replays scipy's augmentation order and tie rule (NIF_LAP_SCIPY_ORDER) runs.  scipy_order='replay' forces that
     kernel.  ``lap_solve.last_path`` names the path taken ('fast', 'certified', 'replay').
@@ -176,14 +243,20 @@ def lap_solve(C, duals=False, scipy_order=False):
         if scipy_order is True and n >= 32:
             path = 'replay'
             run(_lib.NIF_LAP_INIT_ONLY)
-            free = int((col < 0).sum().item())
-            if free * 8 <= n:  # nearly solved by the dual initialisation
-                # a budget of Dijkstra steps keeps a hard instance from being solved twice: what the budget leaves
-                # unmatched fails the certificate
-                run(_lib.NIF_LAP_RESUME | ((16 * free + 64) << _lib.NIF_LAP_BUDGET_SHIFT))
+            free, dup = torch.stack([(col < 0).sum(), _has_duplicate_lines(C).long()]).tolist()   # one read-back
+            if free * 8 <= n or not dup:
+                # nearly solved by the dual initialisation: a budget of Dijkstra steps keeps a hard instance from being
+                # solved twice (what the budget leaves unmatched fails the certificate).  Not nearly solved, but no two
+                # rows or columns alike (unrelated trained models): the fast solver -- augmenting row reduction + the
+                # remaining searches, several times quicker than the replay -- and the same certificate; a failed
+                # certificate (an ambiguous optimum after all) costs that solve and falls through to the replay.
+                budget = ((16 * free + 64) << _lib.NIF_LAP_BUDGET_SHIFT) if free * 8 <= n else 0
+                run(_lib.NIF_LAP_RESUME | budget)
                 cnt = torch.empty(1, dtype=torch.int32, device=C.device)
-                check(lib.nif_lap_count_tight_f32(_ptr(C), _ld(C), n, _ptr(col), _ptr(u), _ptr(v), LAP_CERT_TOL,
-                                                  _ptr(cnt), _stream()), 'nif_lap_count_tight_f32')
+                cbytes = lib.nif_lap_certify_workspace_bytes(n)
+                cws = torch.empty(cbytes, dtype=torch.uint8, device=C.device)
+                check(lib.nif_lap_certify_unique_f32(_ptr(C), _ld(C), n, _ptr(col), _ptr(row), _ptr(u), _ptr(v), LAP_CERT_TOL,
+                                                     _ptr(cnt), _ptr(cws), cbytes, _stream()), 'nif_lap_certify_unique_f32')
                 if int(cnt.item()) == 0:
                     path = 'certified'
             if path == 'replay':
@@ -260,18 +333,26 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                 else:
                     run(p, _lib.NIF_LAP_SCIPY_ORDER)
             if staged:
+                for p in staged:
+                    with torch.cuda.stream(p['stream']):
+                        p['dup'] = _has_duplicate_lines(p['C']).long()
                 join()
-                free = torch.stack([(p['col'] < 0).sum() for p in staged]).tolist()   # one read-back for all
+                state = torch.stack([torch.stack([(p['col'] < 0).sum(), p['dup']]) for p in staged]).tolist()   # one read-back
                 certs = []
-                for p, f in zip(staged, free):
-                    if f * 8 <= p['n']:  # nearly solved by the dual initialisation: finish under a step budget, certify
-                        run(p, _lib.NIF_LAP_RESUME | ((16 * f + 64) << _lib.NIF_LAP_BUDGET_SHIFT))
+                for p, (f, dup) in zip(staged, state):
+                    if f * 8 <= p['n'] or not dup:
+                        # nearly solved: finish under a step budget; no two lines alike: full fast solve (see lap_solve)
+                        budget = ((16 * f + 64) << _lib.NIF_LAP_BUDGET_SHIFT) if f * 8 <= p['n'] else 0
+                        run(p, _lib.NIF_LAP_RESUME | budget)
                         with torch.cuda.stream(p['stream']):
                             p['cnt'] = torch.empty(1, dtype=torch.int32, device=dev)
-                            check(lib.nif_lap_count_tight_f32(_ptr(p['C']), _ld(p['C']), p['n'], _ptr(p['col']), _ptr(p['u']),
-                                                              _ptr(p['v']), LAP_CERT_TOL, _ptr(p['cnt']),
-                                                              ctypes.c_void_p(p['stream'].cuda_stream)),
-                                  'nif_lap_count_tight_f32')
+                            cbytes = lib.nif_lap_certify_workspace_bytes(p['n'])
+                            p['cws'] = torch.empty(cbytes, dtype=torch.uint8, device=dev)
+                            check(lib.nif_lap_certify_unique_f32(_ptr(p['C']), _ld(p['C']), p['n'], _ptr(p['col']),
+                                                                 _ptr(p['row']), _ptr(p['u']), _ptr(p['v']), LAP_CERT_TOL,
+                                                                 _ptr(p['cnt']), _ptr(p['cws']), cbytes,
+                                                                 ctypes.c_void_p(p['stream'].cuda_stream)),
+                                  'nif_lap_certify_unique_f32')
                         certs.append(p)
                     else:
                         run(p, _lib.NIF_LAP_SCIPY_ORDER)
@@ -284,8 +365,9 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                             run(p, _lib.NIF_LAP_SCIPY_ORDER)
         join()
         for p in P:  # the per-problem buffers were used on side streams
-            for t in (p['col'], p['row'], p['u'], p['v'], p['ws']):
-                t.record_stream(p['stream'])
+            for t in (p['col'], p['row'], p['u'], p['v'], p['ws'], p.get('cws'), p.get('cnt'), p.get('dup')):
+                if t is not None:
+                    t.record_stream(p['stream'])
         if scipy_order:
             infeasible = torch.stack([(p['col'] < 0).any() for p in P if p['path'] == 'replay'] or
                                      [torch.zeros((), dtype=torch.bool, device=dev)])
@@ -467,15 +549,19 @@ def ls_solve(X, A, normalize=False):
     # ONE collective per layer: [G (block upper triangle when large) | R | na | m] travel as one f64 buffer.
     from . import parallel
     group = SampleSharding._active.group
-    R, _, na = xty(X, A, acc='f64')  # this rank's partial products (no rows_sharded: they are reduced together below)
-    G, _, _ = xty(X, None, acc='f64', norms=False)
     tri = d > 2 * parallel.TRI_BLOCK
-    gpart = parallel.pack_gram_upper(G) if tri else G.reshape(-1).double()
-    buf = torch.cat([gpart, R.reshape(-1).double(), na.double(),
-                     torch.tensor([float(m)], dtype=torch.float64, device=X.device)])
+    if tri:  # the normal matrix as a packed triangle written by its reduction kernel, the rest behind it in the buffer
+        buf, ng = xty_sym_packed(X, acc='f64', tail=d * N + N + 1)
+    else:
+        ng = d * d
+        buf = torch.empty(ng + d * N + N + 1, dtype=torch.float64, device=X.device)
+        xty(X, None, acc='f64', norms=False, out=(buf[:ng].view(d, d), None, None))
+    # this rank's partial products, written in place (no rows_sharded: everything is reduced together below)
+    xty(X, A, acc='f64', out=(buf[ng:ng + d * N].view(d, N), torch.empty(d, dtype=torch.float64, device=X.device),
+                              buf[ng + d * N:ng + d * N + N]))
+    buf[-1] = float(m)
     parallel.all_reduce_sum(buf, group)
-    ng = gpart.numel()
-    G = parallel.unpack_gram_upper(buf[:ng], d, has_na=False)[0] if tri else buf[:ng].view(d, d)
+    G = unpack_upper(buf, d) if tri else buf[:ng].view(d, d)
     R = buf[ng:ng + d * N].view(d, N)
     na = buf[ng + d * N:ng + d * N + N]
     m = int(round(float(buf[-1].item())))
@@ -533,6 +619,14 @@ def kmeans_gram(A, *, rows_sharded=False):
     from .parallel import SampleSharding
     A = _mat(A, 'A')
     _need_gpu(A)
+    if (rows_sharded and A.dtype == torch.float32 and os.environ.get('NIF_KMEANS_G', 'f32') != 'f64' and
+            SampleSharding.wants_packed(A.shape[1])):
+        # sharded, large N: the ranks' partial Grams travel as packed f64 triangles and the reduced triangle is expanded
+        # straight into the f32 storage + f64 diagonal -- the f64 N x N matrix (4.8 GB at N = 24 576) is never formed
+        from . import parallel
+        buf, _ = xty_sym_packed(A, acc='f32')
+        parallel.all_reduce_sum(buf, SampleSharding._active.group)
+        return unpack_upper(buf, A.shape[1], dtype=torch.float32, gdiag=True)
     two_steps = (A.dtype != torch.float32 or os.environ.get('NIF_KMEANS_G', 'f32') == 'f64' or
                  (rows_sharded and SampleSharding._active is not None))
     if two_steps:

@@ -179,6 +179,13 @@ class SampleSharding:
         return False
 
     @classmethod
+    def wants_packed(cls, n):
+        """A symmetric n x n Gram of a sharded run travels as a packed block upper triangle (written by the reduction
+        kernel, ops.xty_sym_packed) when it is large enough for the halved traffic to matter."""
+        return (cls._active is not None and dist.is_initialized() and dist.get_world_size(cls._active.group) > 1 and
+                n > 2 * TRI_BLOCK)
+
+    @classmethod
     def reduce(cls, G, na=None, nb=None, symmetric=False):
         if cls._active is None:
             return G, na, nb

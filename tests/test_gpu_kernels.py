@@ -279,10 +279,55 @@ def test_lap_scipy_order_takes_the_certified_fast_path_on_planted_instances(ops,
     col2, ref2 = _check_lap(ops, C2, scipy_order=True)
     assert ops.lap_solve.last_path == 'replay'
     assert (col2 == ref2).all()
-    # a unique optimum the initialisation does not nearly solve goes to the replay kernel without a fast attempt
+    # a unique optimum the initialisation does not nearly solve, no two rows / columns alike (unrelated trained models):
+    # the fast solver (augmenting row reduction + searches) and the certificate, not the replay kernel
     Cr = torch.rand(n, n, generator=g)
     col3, ref3 = _check_lap(ops, Cr, scipy_order=True)
     assert (col3 == ref3).all()
+    assert ops.lap_solve.last_path == 'certified'
+    # the same with a block of small integers mixed in: ties without duplicated lines fail the certificate -> replay
+    Ct = Cr.clone()
+    Ct[: n // 2, : n // 2] = torch.randint(0, 3, (n // 2, n // 2), generator=g).float()
+    col4, ref4 = _check_lap(ops, Ct, scipy_order=True)
+    assert (col4 == ref4).all()
+
+
+def test_lap_cycle_certificate_accepts_ties_without_a_cycle_and_rejects_an_alternating_cycle(ops):
+    """nif_lap_certify_unique_f32: the augmenting row reduction leaves tight edges outside the matching by construction
+    (the strict certificate counts them), yet a random instance has a unique optimum and the cycle test says so; an
+    exactly ambiguous 2 x 2 block (c00 + c11 == c01 + c10) with no duplicated line must be refused."""
+    from neuron_interpolation_model_fusion_amd import _lib
+    lib = _lib.lib
+    g = torch.Generator().manual_seed(5)
+    n = 200
+    st = torch.cuda.current_stream().cuda_stream
+
+    def verdicts(C):
+        col, row, u, v = ops.lap_solve(C, duals=True)
+        res = torch.full((1,), -1, dtype=torch.int32, device='cuda')
+        strict = torch.empty(1, dtype=torch.int32, device='cuda')
+        nb = lib.nif_lap_certify_workspace_bytes(n)
+        ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+        _lib.check(lib.nif_lap_certify_unique_f32(C.data_ptr(), C.stride(0), n, col.data_ptr(), row.data_ptr(), u.data_ptr(),
+                                                  v.data_ptr(), 1e-9, res.data_ptr(), ws.data_ptr(), nb, st), 'certify')
+        _lib.check(lib.nif_lap_count_tight_f32(C.data_ptr(), C.stride(0), n, col.data_ptr(), u.data_ptr(), v.data_ptr(), 1e-9,
+                                               strict.data_ptr(), st), 'count_tight')
+        return col, int(res.item()), int(strict.item())
+
+    C = torch.rand(n, n, generator=g).cuda()
+    col, res, strict = verdicts(C)
+    ref = linear_sum_assignment(C.cpu().numpy())[1]
+    assert (col.cpu().numpy() == ref).all()
+    assert strict > 0, 'the solver leaves tight edges behind (a bidder\'s best and second-best columns tie)'
+    assert res == 0, 'but they close no cycle: the optimum is unique'
+    Ca = (torch.rand(n, n, generator=g) + 10.0)
+    Ca[:2, :] = 100.0
+    Ca[:, :2] = 100.0
+    Ca[:2, :2] = torch.tensor([[1.0, 2.0], [3.0, 4.0]])   # both matchings of the block cost 5
+    Ca = Ca.cuda()
+    col, res, _ = verdicts(Ca)
+    assert sorted(col[:2].tolist()) == [0, 1]
+    assert res != 0
 
 
 def test_lap_certificate_counts_tight_edges(ops):
@@ -884,6 +929,36 @@ def test_xty_writes_into_caller_buffers(ops):
     assert torch.equal(buf, pack_gram(G, na, nb))
     with pytest.raises(ValueError):
         ops.xty(A, B, out=(G.float(), na, nb))
+
+
+@pytest.mark.parametrize('n,block,acc', [(70, 8, 'f32'), (300, 64, 'f32'), (257, 1024, 'f64'), (3000, 1024, 'f32'),
+                                         (2881, 100, 'f32')])
+def test_xty_sym_packed_equals_packing_the_full_gram(ops, n, block, acc):
+    """The split-K reduction writing the packed block upper triangle (what a sharded run all-reduces) gives the bits
+    of the full symmetric Gram packed afterwards, and nif_unpack_upper the bits of the full matrix (f64, or the f32
+    k-means storage with its f64 diagonal)."""
+    from neuron_interpolation_model_fusion_amd import parallel
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(900, n, generator=g).cuda()
+    G, na, _ = ops.xty(A, None, acc=acc)
+    buf, plen = ops.xty_sym_packed(A, acc=acc, norms=True, block=block, tail=3)
+    assert buf.numel() == plen + n + 3
+    ref = parallel.pack_gram_upper(G, na, block=block)
+    assert ref.numel() == plen + n
+    assert torch.equal(buf[:plen + n], ref)
+    assert torch.equal(ops.unpack_upper(buf, n, block=block), G)
+    Gf, gd = ops.unpack_upper(buf, n, block=block, dtype=torch.float32, gdiag=True)
+    assert torch.equal(Gf, G.float()) and torch.equal(gd, torch.diagonal(G))
+    G2, na2 = parallel.unpack_gram_upper(buf[:plen + n], n, block=block)
+    assert torch.equal(G2, G) and torch.equal(na2, na)
+    # ReLU on load and the transposed operand layout go through the same path
+    bufr, _ = ops.xty_sym_packed(A, acc=acc, relu=True, block=block)
+    Gr, _, _ = ops.xty(A, None, acc=acc, relu_a=True, norms=False)
+    assert torch.equal(ops.unpack_upper(bufr, n, block=block), Gr)
+    At = A.T.contiguous()
+    buft, _ = ops.xty_sym_packed(At, acc=acc, trans=True, block=block)
+    Gt, _, _ = ops.xty(At, None, acc=acc, trans_a=True, norms=False)
+    assert torch.equal(ops.unpack_upper(buft, n, block=block), Gt)
 
 
 # ---- symmetric eigendecomposition with a cutoff (the LS refit's factor step) --------------------------------------
