@@ -335,6 +335,9 @@ int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const floa
 #define NIF_EMD_MAX_N 8192
 #define NIF_EMD_EDGES_GLOBAL 1 /* flags: keep the arc records in the workspace instead of LDS (room for 4 (n0 + n1)
                                   arcs; retry with it when a degenerate problem returns NIF_ERR_WORKSPACE in status) */
+#define NIF_EMD_COLD_START 2   /* flags: square problems normally start from the assignment solution of the same costs
+                                  (nif_lap_solve_f32: feasible duals, a tight perfect matching to ship along); this
+                                  keeps the column-minimum / row-minimum start (tuning aid) */
 size_t nif_emd_workspace_bytes(int n0, int n1);
 int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, const double* a, const double* b, double tol,
                       int flags, int32_t* colptr, int32_t* rowidx, double* val, int32_t out_cap, int32_t* status,

@@ -26,7 +26,8 @@
 namespace nif {
 
 struct EmdWs {
-  size_t off_arc, off_eflow, off_dem, off_sup, off_jbest, off_rowd, off_newrows, off_u, off_v, total;
+  size_t off_arc, off_eflow, off_dem, off_sup, off_jbest, off_rowd, off_newrows, off_u, off_v, off_r4c, off_lap, total;
+  size_t lap_bytes;
   int cap;
 };
 
@@ -48,6 +49,10 @@ static EmdWs emd_ws(int n0, int n1) {
   w.off_newrows = take((size_t)n0 * sizeof(int));
   w.off_u = take((size_t)n0 * sizeof(double));
   w.off_v = take((size_t)n1 * sizeof(double));
+  // square problems start from the assignment solution (see nif_emd_solve_f32): its workspace and row4col
+  w.lap_bytes = n0 == n1 ? nif_lap_workspace_bytes(n0) : 0;
+  w.off_r4c = take(w.lap_bytes ? (size_t)n0 * sizeof(int) : 0);
+  w.off_lap = take(w.lap_bytes);
   w.total = o;
   return w;
 }
@@ -614,9 +619,22 @@ extern "C" int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, co
   double* uu = u ? u : reinterpret_cast<double*>(base + w.off_u);
   double* vv = v ? v : reinterpret_cast<double*>(base + w.off_v);
   clear_err();
-  hipLaunchKernelGGL(emd_colmin_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, C, ldc, n0, n1, vv);
-  hipLaunchKernelGGL(emd_rowmin_kernel, dim3((n0 + 3) / 4), dim3(256), 0, st, C, ldc, n0, n1, vv, uu,
-                     reinterpret_cast<int*>(base + w.off_jbest));
+  const bool warm = w.lap_bytes != 0 && n0 >= 2 && !(flags & NIF_EMD_COLD_START) && !env_int("NIF_EMD_COLD_START");
+  if (warm) {
+    // Square problem: start from the ASSIGNMENT solution of the same costs (uniform marginals) -- its duals are
+    // feasible for any marginals and tight on a perfect matching, so the greedy shipment of the kernel sends
+    // min(a_i, b_j) along every matched pair and only the differences |a_i - b_j| are left to the augmenting paths
+    // (at most one row or column saturates per augmentation: ~n / 2 of them instead of the ~3 n the column-minimum /
+    // row-minimum start needs, and the searches are short because the duals are already near the optimum's).
+    const int rc = nif_lap_solve_f32(C, ldc, n0, 0, reinterpret_cast<int32_t*>(base + w.off_jbest),
+                                     reinterpret_cast<int32_t*>(base + w.off_r4c), uu, vv, base + w.off_lap, w.lap_bytes,
+                                     stream);
+    if (rc != NIF_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(emd_colmin_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, C, ldc, n0, n1, vv);
+    hipLaunchKernelGGL(emd_rowmin_kernel, dim3((n0 + 3) / 4), dim3(256), 0, st, C, ldc, n0, n1, vv, uu,
+                       reinterpret_cast<int*>(base + w.off_jbest));
+  }
   int cpt = 1;
   while (cpt < 8 && (n1 + cpt - 1) / cpt > 1024) cpt *= 2;
   const int threads = ((n1 + cpt - 1) / cpt + 63) / 64 * 64;

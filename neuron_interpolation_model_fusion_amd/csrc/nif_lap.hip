@@ -910,6 +910,7 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
   if (init_only) return NIF_OK;
+  if (timed) prof_begin(NIF_PROF_LAP, st);  // the span covers the row reduction and the augmenting kernel
   if (!scipy_order && n >= 2) {
     // augmenting row reduction before the shortest-path searches: at most 4 n passes of up to 16 bids each
     // (NIF_LAP_ARR_PASSES: tuning aid, -1 = skip the phase, k > 0 = that many passes)
@@ -955,9 +956,11 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
   // columns per lane on the relax work outweighs that (n = 512 on one wave: 1.3 us per step against 0.95)
   if (n > 64 && n <= 128 && cpt_override == 0) cpt = 2;
   int threads = ((n + cpt - 1) / cpt + 63) / 64 * 64;
-  if (threads > 1024) return NIF_ERR_UNSUPPORTED;
+  if (threads > 1024) {
+    if (timed) prof_end(NIF_PROF_LAP, st);
+    return NIF_ERR_UNSUPPORTED;
+  }
   const size_t lds = (size_t)((3 * n + 3) & ~3) * sizeof(int) + LAP_MBOX_TOTAL * sizeof(int);
-  if (timed) prof_begin(NIF_PROF_LAP, st);
 #define NIF_LAP_GO(CPT, ONE)                                                                       \
   do {                                                                                        \
     if (scipy_order) launch_augment<CPT, true, ONE>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, 0); \

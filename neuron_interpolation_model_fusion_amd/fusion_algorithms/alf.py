@@ -291,14 +291,18 @@ class ALFusion:
                 iters += 1
                 prev = assignment
                 assignment, nearest, cost, _ = km.lloyd_step(prev)
-                n_empty = target_width - torch.unique(assignment).numel()
-                if n_empty > 0:
+                # ONE read-back per iteration: (distinct labels, cost, labels changed) -- the reference's loop asks
+                # the device three separate questions here (alf.py:245-247,264)
+                distinct = (torch.bincount(assignment.long(), minlength=target_width) > 0).sum()
+                n_distinct, current_cost, chg = torch.stack(
+                    [distinct.double(), cost, (assignment != prev).any().double()]).tolist()
+                changed = chg != 0.0
+                if int(n_distinct) < target_width:  # a cluster went empty: the rare path, on the host (see _repair_on_host)
                     a_host, d_host = self._repair_on_host(assignment, nearest, target_width)
                     assignment = a_host.to(device=dev, dtype=torch.int32)
-                    current_cost = float(torch.sum(d_host.to(dev) * sw64).item())
-                else:
-                    current_cost = float(cost.item())
-                changed = bool((assignment != prev).any().item())
+                    current_cost, chg = torch.stack([torch.sum(d_host.to(dev) * sw64),
+                                                     (assignment != prev).any().double()]).tolist()
+                    changed = chg != 0.0
                 if len(costs_log) >= 3 and current_cost >= costs_log[-3]:
                     print("K-means Early Stopping at ", len(costs_log), " iterations since ", current_cost, " >= ",
                           costs_log[-3], "*", 1.0)

@@ -11,6 +11,8 @@ every rank computes the identical result from the identical reduced buffer, so n
 needed.  torch.distributed's "nccl" backend is RCCL on ROCm; "gloo" runs the same code on CPU
 tensors (tests/test_parallel_gloo.py).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -58,12 +60,42 @@ def _via_host(t, group=None):
     return t.is_cuda and dist.get_backend(group) != 'nccl'
 
 
+DIRECT_MIN_BYTES = 8 << 20  # below this one library all-reduce is latency-bound either way
+
+
+def _direct_all_reduce(buf, group=None):
+    """Sum over the group as a DIRECT reduce-scatter + all-gather: the 8 GPUs of a node are a full
+    xGMI mesh, 7 links x ~153 GB/s each, so every rank sends chunk r of its buffer straight to rank r (all links busy
+    at once, one hop), sums the chunks it received in rank order, and sends its reduced chunk straight to everybody --
+    2 (S / W) bytes per link against the 2 (W - 1) (S / W) of a ring, which is per-link bound on a mesh.  The sum is
+    formed in one fixed order on one rank per chunk, so every rank ends with the same bits whatever the library would
+    have chosen.  Two all-to-alls (RCCL: concurrent point-to-point sends)."""
+    W = dist.get_world_size(group)
+    n = buf.numel()
+    chunk = (n + W - 1) // W
+    send = buf if n == W * chunk else torch.cat([buf, buf.new_zeros(W * chunk - n)])
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)            # recv[r] = chunk `me` of rank r
+    mine = recv.view(W, chunk)[0].clone()
+    for r in range(1, W):                                       # rank order: a fixed summation order
+        mine += recv.view(W, chunk)[r]
+    out = torch.empty_like(send)
+    dist.all_to_all_single(out, mine.repeat(W), group=group)   # out[r] = reduced chunk r, straight from its owner
+    buf.copy_(out[:n])
+    return buf
+
+
 def all_reduce_sum(buf, group=None):
-    """In-place sum of `buf` over the group."""
+    """In-place sum of `buf` over the group.  RCCL: large buffers go through the direct reduce-scatter + all-gather
+    when NIF_ALLREDUCE=direct (off by default: it could only be rehearsed with one rank on the one-GPU box; the
+    library all-reduce is the path every multi-rank test here exercises)."""
     if _via_host(buf, group):
         host = buf.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         buf.copy_(host)
+    elif (os.environ.get('NIF_ALLREDUCE') == 'direct' and buf.is_cuda and
+          buf.numel() * buf.element_size() >= DIRECT_MIN_BYTES):
+        _direct_all_reduce(buf, group)
     else:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf

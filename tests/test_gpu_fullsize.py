@@ -85,8 +85,10 @@ def test_c3_assignment_at_full_size(ops):
     assert worst > -1e-9 * float(C.abs().max())
 
 
-def test_c4_kmeans_at_full_size(ops):
-    """C4: ALF k-means of two ViT levels: m = 325 000 rows, N = 768 neurons, k = 384 clusters."""
+@pytest.mark.parametrize('storage', ['f64', 'gf32'])
+def test_c4_kmeans_at_full_size(ops, storage):
+    """C4: ALF k-means of two ViT levels: m = 325 000 rows, N = 768 neurons, k = 384 clusters -- on the f64 Gram and on
+    the storage the fusions use by default (ops.kmeans_gram: f32 entries + f64 diagonal, written by the reduction)."""
     m, h = 325000, 384
     A0, A1, _ = _planted(m, h, 5, noise=0.5)
     A = torch.cat([A0, A1], dim=1).contiguous()
@@ -95,7 +97,12 @@ def test_c4_kmeans_at_full_size(ops):
     assert torch.equal(G, G.T)
     assert torch.allclose(G.diagonal(), na, rtol=1e-6)
     s = torch.ones(N, device='cuda')
-    km = ops.KMeans(G, na, s, k)
+    if storage == 'gf32':
+        Gs, gdiag = ops.kmeans_gram(A)
+        assert Gs.dtype == torch.float32 and torch.equal(Gs, G.float()) and torch.equal(gdiag, G.diagonal())
+        km = ops.KMeans(Gs, gdiag, s, k, gdiag=gdiag)
+    else:
+        km = ops.KMeans(G, na, s, k)
     assign = km.assign_to_neurons(0)  # centroids start at model 0's neurons (alf.py:216-226)
     costs = []
     for _ in range(6):
@@ -191,6 +198,67 @@ def test_c5_width_3072_shard_and_kmeans(ops):
     assert picks.cpu().tolist() == ref_picks
     assert torch.equal(assign.long(), lab)
     # Lloyd: the objective never increases; labels stay in range
+    costs = []
+    for _ in range(4):
+        assign, nearest, cost, kprime = km.lloyd_step(assign)
+        costs.append(float(cost))
+    assert all(b <= a * (1 + 1e-9) for a, b in zip(costs, costs[1:])), costs
+    labl = assign.long()
+    assert int(labl.min()) >= 0 and int(labl.max()) < k
+    T, kp = km.targets(A, assign)
+    present = torch.unique(labl)
+    assert int(kp) == present.numel()
+    for idx in (0, present.numel() // 2, present.numel() - 1):
+        members = (labl == present[idx]).nonzero().squeeze(1)
+        refc = A[:, members].double().mean(dim=1)
+        assert torch.allclose(T[:, idx].double(), refc, rtol=1e-5, atol=1e-6)
+
+
+def test_c5_width_3072_kmeans_on_the_default_f32_gram_storage(ops):
+    """The same C5 level through what the fusions actually run (ops.kmeans_gram -> nif_xty_sym_gf32, the _gf32 k-means
+    entry points): multi-workgroup farthest-point picks against the sequential definition evaluated on the same stored
+    values, Lloyd objective non-increasing, labels agreeing with the f64-storage run, targets = cluster means; and the
+    packed-triangle route a sharded run takes (xty_sym_packed -> unpack_upper) giving the same storage bit for bit."""
+    m, N, k = 25000, 24576, 3072
+    g = torch.Generator(device='cuda').manual_seed(11)
+    base = torch.randn(m, k, device='cuda', generator=g)
+    A = torch.empty(m, N, device='cuda')
+    for j in range(8):
+        perm = torch.randperm(k, device='cuda', generator=g)
+        A[:, j * k:(j + 1) * k] = base[:, perm] + 0.5 * torch.randn(m, k, device='cuda', generator=g)
+    del base
+    G, gdiag = ops.kmeans_gram(A)
+    assert G.dtype == torch.float32 and G.shape == (N, N)
+    buf, plen = ops.xty_sym_packed(A)
+    assert plen < 0.53 * N * N
+    G2, gd2 = ops.unpack_upper(buf, N, dtype=torch.float32, gdiag=True)
+    for r0 in range(0, N, 4096):
+        assert torch.equal(G2[r0:r0 + 4096], G[r0:r0 + 4096])
+    assert torch.equal(gd2, gdiag)
+    del G2, buf
+    s = torch.ones(N, device='cuda')
+    km = ops.KMeans(G, gdiag, s, k, gdiag=gdiag)
+    first = 17
+    picks, assign = km.farthest_init(first)
+    assert km.farthest_init_redo_count() >= 0
+    p = first
+    mind = lab = None
+    ref_picks = [first]
+    for c in range(k):
+        row = G[p].double()
+        row[p] = gdiag[p]   # the kernels take the diagonal from its own f64 array
+        d = (gdiag[p] - 2 * row + gdiag).clamp_min(0).sqrt()
+        if c == 0:
+            mind, lab = d.clone(), torch.zeros(N, dtype=torch.long, device='cuda')
+        else:
+            upd = d < mind
+            mind = torch.where(upd, d, mind)
+            lab = torch.where(upd, torch.full_like(lab, c), lab)
+        if c + 1 < k:
+            p = int(torch.argmax(mind))
+            ref_picks.append(p)
+    assert picks.cpu().tolist() == ref_picks
+    assert torch.equal(assign.long(), lab)
     costs = []
     for _ in range(4):
         assign, nearest, cost, kprime = km.lloyd_step(assign)

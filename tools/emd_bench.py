@@ -5,11 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuron_interpolation_model_fusion_amd import ops
 
 def run(tag, C, a, b):
-    ops.emd_solve(C, a, b); torch.cuda.synchronize()
-    t0 = time.perf_counter(); plan = ops.emd_solve(C, a, b); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    w = ops.emd_solve.last_work
-    print(f'{tag}: {C.shape[0]}x{C.shape[1]} {dt*1e3:.1f} ms, nnz {plan.nnz}, {w}, {dt*1e6/max(w["steps"],1):.2f} us/step', flush=True)
+    for cold in (('1', '0') if C.shape[0] == C.shape[1] else ('0',)):
+        os.environ['NIF_EMD_COLD_START'] = cold   # 1: column / row minimum start; 0: from the assignment solution (square)
+        ops.emd_solve(C, a, b); torch.cuda.synchronize()
+        t0 = time.perf_counter(); plan = ops.emd_solve(C, a, b); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        w = ops.emd_solve.last_work
+        cost = float((plan.dense(torch.float64) * C.double()).sum())
+        print(f'{tag} [{"cold" if cold == "1" else "warm"}]: {C.shape[0]}x{C.shape[1]} {dt*1e3:.1f} ms, nnz {plan.nnz}, {w}, '
+              f'{dt*1e6/max(w["steps"],1):.2f} us/step, cost {cost:.9f}', flush=True)
+    os.environ.pop('NIF_EMD_COLD_START', None)
 
 g = torch.Generator(device='cuda').manual_seed(0)
 for n0, n1 in ((384, 384), (512, 512), (1024, 1024), (2100, 1500)):
