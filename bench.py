@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 M_ROWS = 5000 * 65
 WIDTH = 384
 FAN_IN = 384
-TRAFFIC_FILE = 'r2_xty_traffic.json'  # written by tools/pmc_kernel.py from the PMC passes of this round's kernel
+TRAFFIC_FILE = 'r3_xty_traffic.json'  # written by tools/pmc_kernel.py from the PMC passes of this round's kernel
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 

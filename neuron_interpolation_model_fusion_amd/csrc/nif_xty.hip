@@ -108,6 +108,12 @@ struct StageRows {
         r[h] = x;
       }
     }
+  }
+
+  // ReLU on load (Git Re-Basin's post-activation Gram): applied when the staged registers are COMMITTED, not where
+  // they are loaded -- clamping right behind the loads made the kernel wait for them at once, and the tile's global
+  // latency, which the MFMA groups between load and commit are there to cover, was exposed (C3: 103 -> 121 TF)
+  static __device__ __forceinline__ void activate(V4<T> (&r)[PASSES]) {
     if (RELU) {
 #pragma unroll
       for (int h = 0; h < PASSES; ++h)
@@ -181,6 +187,8 @@ struct StageCols {
       r[h] = x;
     }
   }
+
+  static __device__ __forceinline__ void activate(V4<T> (&)[PASSES]) {}  // ReLU on load: row-major operands only
 
   template <int LD>
   static __device__ __forceinline__ void put(T* __restrict__ L, const V4<T> (&r)[PASSES], int tid) {
@@ -388,10 +396,12 @@ __global__ __launch_bounds__(NT, (xty_waves_per_simd<MmaT, FI>())) void xty_kern
   auto stage_a = [&](int64_t k0) { SA::load(ra, A, p.lda, k0, k_end, ci, p.n0, p.vec_a, tid); };
   auto stage_b = [&](int64_t k0) { SB::load(rb, B, p.ldb, k0, k_end, cj, p.n1, p.vec_b, tid); };
   auto commit_a = [&](int buf) {
+    SA::activate(ra);
     SA::template put<LDA>(smem + buf * (TILE_A + TILE_B), ra, tid);
     if (want_a) SA::norms(sqa, ra);
   };
   auto commit_b = [&](int buf) {
+    SB::activate(rb);
     SB::template put<LDB>(smem + buf * (TILE_A + TILE_B) + TILE_A, rb, tid);
     if (want_b) SB::norms(sqb, rb);
   };
@@ -915,7 +925,8 @@ struct XtyPlan {
   size_t slab_bytes, nsa_bytes, nsb_bytes, lds_bytes;
 };
 
-static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, int flags, int slot_div = 1) {
+static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, int flags, int slot_div = 1,
+                        int force_splits = 0) {
   XtyPlan pl;
   pl.f = f;
   pl.tm = 64 * f;
@@ -933,7 +944,7 @@ static XtyPlan plan_for(int f, int64_t m, int n0, int n1, int in_f64, int acc, i
   if (slots_override >= 1) pl.slots = slots_override;
   int64_t target = pl.slots;
   if (pl.ntiles > target) target = pl.ntiles;
-  int64_t splits = target / pl.ntiles;
+  int64_t splits = force_splits > 0 ? force_splits : target / pl.ntiles;
   const int64_t max_splits = (m + 4 * BK - 1) / (4 * BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -990,6 +1001,21 @@ static XtyPlan make_plan(int64_t m, int n0, int n1, int in_f64, int acc, int fla
         best = pl;
         best_cost = c;
         have = true;
+      }
+      // When the output tiles alone fill the chip the rows are not split, and a last, partly filled round of
+      // workgroups can cost up to half the kernel (symmetric N = 6144: 1176 tiles on 768 slots = 2 rounds for 1.53
+      // rounds of work).  A few row splits put the block count next to a multiple of the slots; the price is their
+      // slabs in the reduction (and in the workspace: capped at 1 GiB of slabs).
+      if (pl.splits == 1 && pl.ntiles >= pl.slots / 2) {
+        for (int sp = 2; sp <= 12; ++sp) {
+          const XtyPlan ps = plan_for(f, m, n0, n1, in_f64, acc, flags, div, sp);
+          if (ps.splits != sp || ps.slab_bytes > ((size_t)1 << 30)) continue;
+          const double cs = plan_cost(ps, div, f64_path, esz, (flags & NIF_XTY_SPLIT_BF16) != 0);
+          if (cs < best_cost) {
+            best = ps;
+            best_cost = cs;
+          }
+        }
       }
     }
   }
