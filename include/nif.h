@@ -338,6 +338,10 @@ int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const floa
 #define NIF_EMD_COLD_START 2   /* flags: square problems normally start from the assignment solution of the same costs
                                   (nif_lap_solve_f32: feasible duals, a tight perfect matching to ship along); this
                                   keeps the column-minimum / row-minimum start (tuning aid) */
+#define NIF_EMD_ARC_POOL 4     /* flags: the first-generation kernel (support kept as an arc pool swept level by level)
+                                  instead of the rooted-forest kernel that runs wherever it fits (n1 <= 2048): A/B aid */
+#define NIF_EMD_ONE_LANE_PATHS 8 /* flags: the forest kernel walks every augmenting path with its general one-lane code
+                                  (taken by itself only for paths over more than 32 trees or 64 arcs a side): test aid */
 size_t nif_emd_workspace_bytes(int n0, int n1);
 int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, const double* a, const double* b, double tol,
                       int flags, int32_t* colptr, int32_t* rowidx, double* val, int32_t out_cap, int32_t* status,

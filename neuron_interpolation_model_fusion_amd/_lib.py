@@ -28,6 +28,8 @@ NIF_EIGH_MAX_N = 6144
 NIF_LSQ_NORMALIZE, NIF_LSQ_PRIMAL = 1, 2
 NIF_EMD_EDGES_GLOBAL = 1
 NIF_EMD_COLD_START = 2
+NIF_EMD_ARC_POOL = 4
+NIF_EMD_ONE_LANE_PATHS = 8
 NIF_ERR_WORKSPACE = -2
 
 _c = ctypes

@@ -250,6 +250,12 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
 
   int step = 0, n_aug = 0, n_expand = 0;
   int lvl = 0;  // sweep level counter, never reused
+#ifdef NIF_EMD_TIMING  // cycles per phase into status[4..9] (status must then hold 16 words): tools/emd_timing.py
+  long long tk[6] = {0, 0, 0, 0, 0, 0}, tk0 = wall_clock64();
+#define EMD_MARK(p) do { const long long t_ = wall_clock64(); tk[p] += t_ - tk0; tk0 = t_; } while (0)  // 100 MHz
+#else
+#define EMD_MARK(p) do {} while (0)
+#endif
   long budget = 64L * (n0 + n1) + 1024;  // augmentations; far above the n0 + n1 a non-degenerate problem needs
   for (int i0 = 0; i0 < n0; ++i0) {
     double r = sup[i0];
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
       bool from_rows = true;  // the first sweep starts from the root row, later ones from a settled column
       for (int it = 0; it <= n1 + 1; ++it) {
         // ---- sweep the support component at distance D -----------------------------------------------
+        EMD_MARK(4);
         const int first_lvl = from_rows ? lvl : lvl + 1;  // levels whose rows are new in this sweep
         const int hwm = ctl[2];
         for (;;) {
@@ -325,6 +332,7 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
             dist[c] = D;
           }
         }
+        EMD_MARK(0);
         if (sink >= 0) break;
 
         // ---- rows reached by this sweep, in row order (wave 0 compacts them) --------------------------
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
         __syncthreads();
         const int nnew = ctl[7];
         n_expand += nnew;
+        EMD_MARK(1);
         int k = 0;
         constexpr int RB = CPT <= 2 ? 8 : 4;  // cost rows in flight
         for (; k + RB - 1 < nnew; k += RB) {
@@ -394,6 +403,7 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
           }
         }
 
+        EMD_MARK(2);
         // ---- nearest unsettled column ---------------------------------------------------------------
         double bv = INFINITY;
         int bj = INT_MAX, bf = 0;
@@ -434,6 +444,7 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
         }
         bj = gkey == 0xffffffffu ? INT_MAX : (int)(gkey & 0x7fffffffu);
         bf = (gkey & 0x80000000u) ? 0 : 1;
+        EMD_MARK(3);
         if (bj == INT_MAX || !(bv < INFINITY)) break;  // nothing reachable is left
         D = bv;
         if (bf) {
@@ -533,6 +544,10 @@ __global__ __launch_bounds__(1024) void emd_kernel(const float* __restrict__ C, 
     status[1] = n_aug;  // work counters: augmentations, reductions, rows relaxed
     status[2] = step;
     status[3] = n_expand;
+#ifdef NIF_EMD_TIMING
+    for (int q = 0; q < 6; ++q) status[4 + q] = (int)tk[q];
+    status[10] = lvl;
+#endif
     ctl[3] = err;
   }
   __syncthreads();
@@ -562,6 +577,771 @@ static void launch_emd(int threads, const EmdLds& L, hipStream_t st, const float
                      reinterpret_cast<double*>(base + w.off_sup), reinterpret_cast<double*>(base + w.off_rowd),
                      reinterpret_cast<int*>(base + w.off_newrows), BIG_LDS ? L.cap_lds : w.cap, L, out_cap, colptr,
                      rowidx, val, status);
+}
+
+// =====================================================================================================================
+// Second solver (the default wherever it fits: n1 <= 2048 and the LDS plan below): the same successive shortest
+// paths, with the support kept as a ROOTED FOREST instead of an arc pool.
+//
+// A vertex of the transport polytope is a forest over rows + columns, and every support arc is tight and carries
+// flow, so it can be walked both ways at no cost: for the search, a tree of the forest is ONE node.  The kernel
+// above finds "everything that hangs off this column" by a level-synchronous sweep over the arc pool in every
+// Dijkstra step (48 % of its time at 384 x 384, 6.9 levels of two barriers per step) and relaxes the rows it reached
+// eight at a time with all lanes on one row (21 %).  Here
+//   * every node carries the label of its tree (comp = the tree's root), so "settle the tree of column j" is a label
+//     comparison per column and per row -- no sweep, no list, no barrier;
+//   * every WAVE owns all the columns (lane + 64 c, distances and predecessors in registers) and a share of the rows
+//     (row i belongs to wave i mod NW): a step's rows are relaxed by all waves at once, each streaming its own cost
+//     rows, and the true distance of a column is the minimum over the waves' partial ones -- which the argmin
+//     reduction takes anyway, so the partial distances are never combined;
+//   * the path inside a tree comes from parent pointers (entry node -> lowest common ancestor -> exit node), the flow of
+//     an arc is stored at its child, an arc that runs empty cuts its child loose, a new arc re-roots the entered tree at
+//     its entry column and hangs it under the row it was relaxed from; labels of the trees on the path are then rebuilt
+//     by pointer jumping.  All of it is LDS work; one barrier per Dijkstra step.
+// Duals, tolerances, the start and the plan that comes out follow the kernel above (same optimal cost; where the
+// optimum is not unique the vertex may differ).
+// =====================================================================================================================
+struct __attribute__((aligned(16))) EmdNode {  // one ds_read_b128 per hop of a walk
+  double flow;  // flow of the arc (node, parent)
+  int parent;   // rows 0..n0-1, column j = n0 + j; -1: root
+  int stamp;    // on a root: the search that settled its tree; on any node: tags of the path walks
+};
+
+struct EmdTreeLds {  // byte offsets into dynamic LDS
+  int off_nodes, off_comp, off_entry, off_pred, off_dset, off_plist, off_cxy, off_red, off_v, off_cdist, off_dem;
+  int big;  // 1: cdist and dem live in the workspace
+  size_t bytes;
+};
+
+constexpr int EMD_PL = 4096;  // path records kept in LDS (64 per lane of wave 0); a longer path spills into the workspace
+
+static EmdTreeLds emd_tree_lds(int n0, int n1, int cpl, bool big) {
+  EmdTreeLds L;
+  const int N = n0 + n1;
+  const int n1p = 64 * cpl;  // one slot per lane and column group: v, the column labels and the demand bits are padded
+                             // to it, so that slot (lane, c) is read at a constant offset from a per-lane address
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += (bytes + 15) & ~(size_t)15;
+    return (int)at;
+  };
+  L.off_nodes = take((size_t)N * sizeof(EmdNode));
+  L.off_v = take((size_t)n1p * 8);
+  L.off_red = take(2 * 16 * 8 + 2 * 16 * 4 + 16 * 4 + 4 * 8);  // redv, redk, ctl, dctl
+  L.big = big ? 1 : 0;
+  L.off_cdist = big ? 0 : take((size_t)N * 8);
+  L.off_dem = big ? 0 : take((size_t)n1 * 8);
+  L.off_comp = take((size_t)(n0 + n1p) * 4);
+  L.off_entry = take((size_t)N * 4);
+  L.off_pred = take((size_t)n1 * 4);
+  L.off_dset = take((size_t)(n1p / 32) * 4);
+  L.off_plist = take((size_t)EMD_PL * 4);
+  L.off_cxy = take(64 * 4);
+  L.bytes = o;
+  return L;
+}
+
+#ifdef NIF_EMD_TIMING  // cycles per phase into status[4..9], hop counts into [11..13] (status must hold 16 words)
+#define EMD_COUNT(p) ++hops[p]
+#else
+#define EMD_COUNT(p) do {} while (0)
+#endif
+
+template <int CPL, int NW, bool BIG>
+__global__ __launch_bounds__(NW * 64) void emd_tree_kernel(const float* __restrict__ C, int64_t ldc, int n0, int n1,
+                                                           const double* __restrict__ a, const double* __restrict__ b,
+                                                           double tol, double* __restrict__ u, double* __restrict__ vg,
+                                                           const int* __restrict__ jbest, double* __restrict__ dem_g,
+                                                           double* __restrict__ sup, double* __restrict__ cdist_g,
+                                                           int* __restrict__ plist_g, EmdTreeLds L, int one_lane,
+                                                           int out_cap, int* __restrict__ colptr,
+                                                           int* __restrict__ rowidx, double* __restrict__ val,
+                                                           int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char emd_tsm[];
+  const int N = n0 + n1;
+  EmdNode* nodes = reinterpret_cast<EmdNode*>(emd_tsm + L.off_nodes);  // [N]
+  double* vl = reinterpret_cast<double*>(emd_tsm + L.off_v);           // [n1] column duals
+  double* redv = reinterpret_cast<double*>(emd_tsm + L.off_red);       // [2][16]
+  unsigned* redk = reinterpret_cast<unsigned*>(redv + 32);             // [2][16]
+  // 0: error, 1: tick after the augmentation, 2: rows relaxed, 3: trees on the path / path records, 4..6: relabel
+  // round flags, 7: the path needs the one-lane code, 8: an arc was cut
+  int* ctl = reinterpret_cast<int*>(redk + 32);
+  double* dctl = reinterpret_cast<double*>(ctl + 16);  // 0: amount pushed by the last augmentation
+  double* cdist = BIG ? cdist_g : reinterpret_cast<double*>(emd_tsm + L.off_cdist);  // [N] by root: distance of a settled tree
+  double* dem = BIG ? dem_g : reinterpret_cast<double*>(emd_tsm + L.off_dem);        // [n1] demand left
+  int* comp = reinterpret_cast<int*>(emd_tsm + L.off_comp);      // [N] root of the node's tree
+  int* entry = reinterpret_cast<int*>(emd_tsm + L.off_entry);    // [N] by root: node through which the search entered the tree
+  int* pred_row = reinterpret_cast<int*>(emd_tsm + L.off_pred);  // [n1] row a column was relaxed from (when it was chosen)
+  unsigned* dset = reinterpret_cast<unsigned*>(emd_tsm + L.off_dset);  // columns with demand left
+  int* plist = reinterpret_cast<int*>(emd_tsm + L.off_plist);  // path records: LCAP per lane of wave 0
+  int* cxy = reinterpret_cast<int*>(emd_tsm + L.off_cxy);      // (entry node, exit node) of the trees on the path
+
+  constexpr int T = NW * 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- start: v from the caller's duals, every row ships along its tight arc (i, jbest_i) in row order ------------
+  for (int k = tid; k < N; k += T) {
+    EmdNode nd;
+    nd.flow = 0.0;
+    nd.parent = -1;
+    nd.stamp = 0;
+    nodes[k] = nd;
+    entry[k] = (k < n0) ? jbest[k] : -1;  // (borrowed for the start)
+  }
+  for (int j = tid; j < 64 * CPL; j += T) {
+    vl[j] = j < n1 ? vg[j] : 0.0;
+    if (j >= n1) comp[n0 + j] = -2;  // (no tree)
+  }
+  for (int k = tid; k < 2 * CPL; k += T) dset[k] = 0u;
+  if (tid < 16) ctl[tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < n1; j += T) {
+    double d = b[j];
+    for (int i = 0; i < n0; ++i) {
+      if (entry[i] != j) continue;
+      double sl = a[i];
+      const double x = fmin(sl, d);
+      if (x > tol) {
+        nodes[i].parent = n0 + j;
+        nodes[i].flow = x;
+        const double left = d - x;
+        d = left > tol ? left : 0.0;
+        sl -= x;
+      }
+      sup[i] = sl > tol ? sl : 0.0;
+    }
+    dem[j] = d;
+    if (d > tol) atomicOr(&dset[j >> 5], 1u << (j & 31));
+  }
+  for (int i = tid; i < n0; i += T) {
+    const int j = entry[i];
+    if (j < 0 || j >= n1) {  // a cost row without a finite entry has no tight arc
+      const double sl = a[i];
+      sup[i] = sl > tol ? sl : 0.0;
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < N; k += T) {
+    const int p = nodes[k].parent;
+    comp[k] = p >= 0 ? p : k;  // stars: depth one
+    entry[k] = -1;
+  }
+  __syncthreads();
+
+  // the cost matrix as a buffer resource (range-checked loads)
+  const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(C), 0, (int)((((unsigned)(n0 - 1)) * (unsigned)ldc + (unsigned)n1) * 4u), 0x00020000);
+  unsigned invalid = 0;  // column slots of this lane beyond n1
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+    if (lane + 64 * c >= n1) invalid |= 1u << c;
+
+  int tick = 0, step = 0, n_aug = 0, n_rel = 0;
+#ifdef NIF_EMD_TIMING
+  long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk0 = wall_clock64();
+  int hops[3] = {0, 0, 0};
+#endif
+  long budget = 64L * N + 1024;  // augmentations; far above the n0 + n1 a non-degenerate problem needs
+  bool stop = false;
+  for (int g0 = 0; g0 < n0 && !stop; g0 += 64) {
+    const int gi = g0 + lane;
+    const double sv = gi < n0 ? sup[gi] : 0.0;
+    unsigned long long roots = __ballot(sv > tol);
+    while (roots && !stop) {
+      const int bit = __ffsll((long long)roots) - 1;
+      roots &= roots - 1;
+      const int i0 = g0 + bit;
+      double r = __shfl(sv, bit, 64);
+      while (r > tol) {
+        if (--budget < 0 || ctl[0] != 0) {
+          stop = true;
+          break;
+        }
+        // ---- one search: Dijkstra over the trees of the forest ----------------------------------------------------
+        unsigned smask = invalid, defm = 0;
+        double dist[CPL];
+        int pred[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          dist[c] = ((invalid >> c) & 1u) ? 0.0 : INFINITY;
+          pred[c] = -1;
+          if ((dset[2 * c + (lane >> 5)] >> (lane & 31)) & 1u) defm |= 1u << c;  // column lane + 64 c
+        }
+        const int s = ++tick;
+        int K = comp[i0], e = i0, sink = -1;
+        double D = 0.0;
+        for (int it = 0; it <= N; ++it) {
+          if (tid == 0) {
+            nodes[K].stamp = s;
+            cdist[K] = D;
+            entry[K] = e;
+          }
+          // columns of tree K: settled at distance D (labels read without a guard: a guarded LDS read per column
+          // makes the reads wait for one another)
+          int lab[CPL];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            lab[c] = comp[n0 + lane + 64 * c];
+          }
+          unsigned newly = 0;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            if (lab[c] == K) {
+              newly |= 1u << c;
+            }
+          }
+          newly &= ~smask;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+            if ((newly >> c) & 1u) dist[c] = D;
+          smask |= newly;
+          const unsigned hit = newly & defm;
+          const unsigned cand = wave_min_u32(hit ? (unsigned)(lane + 64 * (__ffs((int)hit) - 1)) : 0xffffffffu);
+          if (cand != 0xffffffffu) {  // the tree holds a column with demand left: the search ends inside it
+            sink = (int)cand;
+            break;
+          }
+          EMD_MARK(0);
+          // rows of tree K that belong to this wave (row i: wave i mod NW): their cost rows are relaxed RB at a time, all
+          // loads of a batch in flight together
+          constexpr int RB = CPL <= 8 ? 4 : CPL <= 16 ? 2 : 1;  // (what the register file of NW waves leaves room for)
+          for (int gb = 0; gb < n0; gb += 64 * NW) {
+            const int i = gb + wave + NW * lane;
+            unsigned long long m = __ballot(comp[i < n0 ? i : n0 - 1] == K && i < n0);
+            n_rel += __popcll(m);
+            while (m) {
+              int ri[RB];
+              int nb = 0;  // rows in this batch (wave-uniform, like everything about m)
+#pragma unroll
+              for (int q = 0; q < RB; ++q) {
+                ri[q] = 0;
+                if (m) {
+                  ri[q] = gb + wave + NW * (__ffsll((long long)m) - 1);
+                  m &= m - 1;
+                  ++nb;
+                }
+              }
+              float cv[RB][CPL];
+              double ub[RB];
+#pragma unroll
+              for (int q = 0; q < RB; ++q) {
+                if (q < nb) {
+                  ub[q] = u[ri[q]];
+                  // bounds-checked buffer loads: slot (lane, c) of the row at a constant offset from one per-lane
+                  // address; slots beyond the matrix read 0 (beyond n1 but inside it: the next row), and are never used
+                  const int rowoff = (int)((unsigned)ri[q] * (unsigned)ldc * 4u);
+#pragma unroll
+                  for (int c = 0; c < CPL; ++c)
+                    cv[q][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, lane * 4 + 256 * c, rowoff, 0));
+                }
+              }
+              double vj[CPL];
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) vj[c] = vl[lane + 64 * c];
+#pragma unroll
+              for (int q = 0; q < RB; ++q) {
+                if (q < nb) {
+                  const double base = D - ub[q];
+                  // in stages over the columns, so that independent operations follow one another (one column at a time
+                  // is a chain of seven dependent instructions)
+                  double rr[CPL];
+#pragma unroll
+                  for (int c = 0; c < CPL; ++c) rr[c] = (double)cv[q][c] - vj[c];
+#pragma unroll
+                  for (int c = 0; c < CPL; ++c) rr[c] += base;
+#pragma unroll
+                  for (int c = 0; c < CPL; ++c) {
+                    // settled and out-of-range slots hold a distance <= D <= rr: they never take the update
+                    const bool better = rr[c] < dist[c];
+                    dist[c] = better ? rr[c] : dist[c];
+                    pred[c] = better ? ri[q] : pred[c];
+                  }
+                }
+              }
+            }
+          }
+          EMD_MARK(1);
+          // nearest unsettled column over all waves' partial distances
+          double bvl = INFINITY;
+          unsigned bk = 0xffffffffu;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            if (!((smask >> c) & 1u)) {
+              const unsigned key = (((defm >> c) & 1u) ? 0u : 0x80000000u) | (unsigned)(lane + 64 * c);
+              if (dist[c] < bvl || (dist[c] == bvl && key < bk)) {
+                bvl = dist[c];
+                bk = key;
+              }
+            }
+          }
+          const double wmin = wave_min_f64(bvl);
+          const unsigned wkey = wave_min_u32((bvl == wmin && bvl < INFINITY) ? bk : 0xffffffffu);
+          const int pb = (step & 1) * 16;
+          ++step;
+          if (lane == 0) {
+            redv[pb + wave] = wmin;
+            redk[pb + wave] = wkey;
+          }
+          EMD_MARK(2);
+          __syncthreads();
+          EMD_MARK(4);
+          double rv[NW];
+          unsigned rk[NW];
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            rv[w] = redv[pb + w];
+            rk[w] = redk[pb + w];
+          }
+          double bv = rv[0];
+          unsigned gkey = rk[0];
+          int wwin = 0;
+#pragma unroll
+          for (int w = 1; w < NW; ++w) {
+            if (rv[w] < bv || (rv[w] == bv && rk[w] < gkey)) {
+              bv = rv[w];
+              gkey = rk[w];
+              wwin = w;
+            }
+          }
+          if (gkey == 0xffffffffu || !(bv < INFINITY)) break;  // nothing reachable is left
+          const int bj = (int)(gkey & 0x7fffffffu);
+          if (wave == wwin && lane == (bj & 63)) {
+            int pv = -1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+              if (c == (bj >> 6)) pv = pred[c];
+            pred_row[bj] = pv;
+          }
+          D = bv;
+          e = n0 + bj;
+          K = comp[e];
+          EMD_MARK(2);
+          if (!(gkey & 0x80000000u)) {  // it has demand left: the path ends at this column, its tree stays unsettled
+            if (tid == 0) entry[K] = e;
+            sink = bj;
+            break;
+          }
+        }
+        __syncthreads();
+        EMD_MARK(0);
+        if (sink < 0) {
+          r = 0.0;  // rounding leftovers with every demand met: this source is done
+          break;
+        }
+        // ---- duals: settled columns move down, reached rows move up, so the support stays tight -------------------
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int j = lane + 64 * c;
+          if ((c % NW) == wave && ((smask & ~invalid) >> c) & 1u) vl[j] += dist[c] - D;
+        }
+        for (int k = tid; k < n0; k += T) {
+          const int kc = comp[k];
+          if (nodes[kc].stamp == s) u[k] += D - cdist[kc];
+        }
+        __syncthreads();
+        EMD_MARK(3);
+        // ---- augmentation ---------------------------------------------------------------------------------------------
+        // The path crosses m trees; inside tree t it runs from the entry node x_t to the exit node y_t along tree arcs
+        // (up to their lowest common ancestor and down again).  Fast path, wave 0: lane 0 lists the (x_t, y_t); lanes
+        // 2t / 2t+1 climb from x_t / y_t in lock step, tagging what they pass with their position, until one steps on
+        // the other's tag (or both step on the same node): max-depth steps for ALL trees at once instead of the sum of
+        // the walks; then every lane prices and updates its own arcs, and lane t re-roots tree t at x_t and hangs it
+        // under the row it was relaxed from.  More than 32 trees or more than LCAP arcs on one side: one lane does it.
+        constexpr int LCAP = EMD_PL / 64;
+        if (tid == 0) {
+          const int K0 = comp[i0];
+          int m = 0, slow = 0;
+          for (int y = n0 + sink;;) {
+            const int Kc = comp[y];
+            const int x = entry[Kc];
+            nodes[Kc].stamp = tick + 1;  // a tag of this augmentation on the root: the tree is relabelled afterwards
+            if (m < 32) {
+              cxy[2 * m] = x;
+              cxy[2 * m + 1] = y;
+            }
+            ++m;
+            if (Kc == K0 || x < n0) break;  // the tree of the source row
+            y = pred_row[x - n0];
+            if (y < 0 || m > N) {
+              ctl[0] = NIF_ERR_UNSUPPORTED;  // cannot happen: every entered tree was relaxed from a row
+              break;
+            }
+          }
+          if (m > 32 || one_lane) slow = 1;
+          ctl[3] = m;
+          ctl[7] = slow;
+          ctl[8] = 0;
+        }
+        __syncthreads();
+        EMD_MARK(6);
+        if (wave == 0 && ctl[7] == 0 && ctl[0] == 0) {
+          const int m = ctl[3];
+          const int t = lane >> 1, side = lane & 1;
+          const bool act = t < m;
+          const int base = tick + 2 + 256 * t;
+          int q = act ? cxy[lane] : -1;
+          int cnt = 0, valid = -1, partner_valid = -1;
+          bool walking = act, over = false;
+          for (int itn = 0; itn <= LCAP + 1; ++itn) {
+            const EmdNode nd = nodes[walking ? q : 0];  // (read before it is known to be needed: one LDS round trip
+            const int oq = __shfl_xor(q, 1, 64);        //  per step together with the two exchanges)
+            const bool owalking = __shfl_xor((int)walking, 1, 64) != 0;
+            if (walking && owalking && q == oq) {  // both arrive here now: the lowest common ancestor
+              walking = false;
+              valid = cnt;
+            }
+            if (!__any(walking)) break;
+            if (walking) {
+              EMD_COUNT(0);
+              const int st = nd.stamp - base;
+              if (st >= 0 && st < 256 && (st & 1) != side) {  // the partner has been here, after st / 2 arcs
+                partner_valid = st >> 1;
+                valid = cnt;
+                walking = false;
+              } else if (cnt >= LCAP) {
+                over = true;
+                walking = false;
+              } else {
+                nodes[q].stamp = base + 2 * cnt + side;
+                plist[lane * LCAP + cnt] = q;
+                ++cnt;
+                if (nd.parent < 0) walking = false;  // at the root: the partner will find the tags
+                else q = nd.parent;
+              }
+            }
+          }
+          const int pv = __shfl_xor(partner_valid, 1, 64);
+          if (valid < 0 && pv >= 0) valid = pv;
+          if (act && valid < 0) over = true;
+          if (__any(over)) {
+            if (lane == 0) ctl[7] = 1;
+          } else {
+            if (valid < 0) valid = 0;
+            // the arcs of all lists, spread over the 64 lanes: lane j takes list j mod P, entries j / P, j / P + 64 / P, ..
+            // Side 0 walked x -> ancestor along the path (arc child -> parent): a column's arc is walked backwards;
+            // side 1 walked y -> ancestor against it: a row's arc is.
+            int lp = 1;
+            while ((1 << lp) < 2 * m) ++lp;
+            const int l = lane & ((1 << lp) - 1), kstep = 64 >> lp;
+            const int lv = __shfl(valid, l, 64);
+            const int lside = l & 1;
+            double lmin = INFINITY;
+            for (int k = lane >> lp; __any(k < lv); k += kstep) {
+              if (k < lv) {
+                const int nq = plist[l * LCAP + k];
+                const bool back = lside ? (nq < n0) : (nq >= n0);
+                if (back) lmin = fmin(lmin, nodes[nq].flow);
+              }
+            }
+            if (lane == 0) lmin = fmin(lmin, fmin(r, dem[sink]));
+            const double delta = wave_min_f64(lmin);
+            int cut = 0;
+            for (int k = lane >> lp; __any(k < lv); k += kstep) {
+              if (k < lv) {
+                EMD_COUNT(1);
+                const int nq = plist[l * LCAP + k];
+                const bool back = lside ? (nq < n0) : (nq >= n0);
+                if (back) {
+                  const double f = nodes[nq].flow - delta;
+                  nodes[nq].flow = f;
+                  if (f <= tol) {  // the arc leaves the support: nq's subtree is a tree of its own
+                    nodes[nq].parent = -1;
+                    cut = 1;
+                  }
+                } else {
+                  nodes[nq].flow += delta;
+                }
+              }
+            }
+            if (__any(cut) && lane == 0) ctl[8] = 1;
+            if (lane < m) {  // new arcs: the entered tree is re-rooted at its entry column and hung under the row
+              const int x = cxy[2 * lane];
+              if (x >= n0) {
+                int prev = -1, guard = N + 1;
+                double pf = 0.0;
+                for (int nq = x; nq >= 0 && --guard > 0;) {
+                  EMD_COUNT(2);
+                  const EmdNode nd = nodes[nq];
+                  nodes[nq].parent = prev;
+                  nodes[nq].flow = pf;
+                  prev = nq;
+                  pf = nd.flow;
+                  nq = nd.parent;
+                }
+                nodes[x].parent = pred_row[x - n0];
+                nodes[x].flow = delta;
+              }
+            }
+            if (lane == 0) {
+              double left = dem[sink] - delta;
+              if (left <= tol) {
+                left = 0.0;
+                dset[sink >> 5] &= ~(1u << (sink & 31));
+              }
+              dem[sink] = left;
+              dctl[0] = delta;
+              ctl[1] = tick + 2 + 256 * m;
+            }
+          }
+        }
+        EMD_MARK(7);
+        __syncthreads();
+        if (ctl[7] != 0 && ctl[0] == 0) {  // the general path, one lane
+          auto put = [&](int idx, int rec) {
+            if (idx < EMD_PL) plist[idx] = rec;
+            else plist_g[idx - EMD_PL] = rec;
+          };
+          auto get = [&](int idx) { return idx < EMD_PL ? plist[idx] : plist_g[idx - EMD_PL]; };
+          if (tid == 0) {
+            const int K0 = comp[i0];
+            int tk = tick + 2 + 256 * 33, np = 0;
+            double delta = fmin(r, dem[sink]);
+            // every walk is over a forest; `guard` only keeps a corrupted structure from spinning (it cannot run out
+            // otherwise: a path visits a node once, and the trees on it are disjoint)
+            int guard = 4 * N + 16;
+            for (int y = n0 + sink; guard > 0;) {
+              const int Kc = comp[y];
+              const int x = entry[Kc];
+              const int tag = ++tk;
+              for (int q = x; q >= 0 && --guard > 0;) {  // x -> root
+                const int up = nodes[q].parent;
+                nodes[q].stamp = tag;
+                q = up;
+              }
+              int q = y;
+              while (q >= 0 && --guard > 0) {  // y -> lowest common ancestor: arcs walked against the path
+                const EmdNode nd = nodes[q];
+                if (nd.stamp == tag) break;
+                const bool back = q < n0;  // column -> row takes flow off the arc
+                if (back) delta = fmin(delta, nd.flow);
+                put(np++, (q << 1) | (back ? 1 : 0));
+                q = nd.parent;
+              }
+              if (q < 0) guard = 0;  // y and its entry node in different trees: cannot happen
+              const int lca = q;
+              for (q = x; q != lca && --guard > 0;) {  // x -> lowest common ancestor: arcs child -> parent
+                const EmdNode nd = nodes[q];
+                const bool back = q >= n0;
+                if (back) delta = fmin(delta, nd.flow);
+                put(np++, (q << 1) | (back ? 1 : 0));
+                q = nd.parent;
+              }
+              if (Kc == K0 || x < n0) break;
+              y = pred_row[x - n0];
+              if (y < 0) guard = 0;
+            }
+            if (guard <= 0) {
+              ctl[0] = NIF_ERR_UNSUPPORTED;
+              np = 0;
+              delta = 0.0;
+            }
+            ctl[1] = tk;
+            ctl[3] = np;
+            ctl[8] = 1;  // (treated as if an arc had been cut: full relabelling)
+            dctl[0] = delta;
+          }
+          __syncthreads();
+          {
+            const int np = ctl[3];
+            const double delta = dctl[0];
+            for (int k = tid; k < np; k += T) {
+              const int rec = get(k);
+              const int q = rec >> 1;
+              if (rec & 1) {
+                const double f = nodes[q].flow - delta;
+                nodes[q].flow = f;
+                if (f <= tol) nodes[q].parent = -1;
+              } else {
+                nodes[q].flow += delta;
+              }
+            }
+          }
+          __syncthreads();
+          if (tid == 0 && ctl[0] == 0) {
+            const double delta = dctl[0];
+            int guard = 4 * N + 16;
+            for (int y = n0 + sink; guard > 0;) {
+              const int x = entry[comp[y]];
+              if (x < n0) break;
+              const int i = pred_row[x - n0];
+              int prev = -1;
+              double pf = 0.0;
+              for (int q = x; q >= 0 && --guard > 0;) {
+                const EmdNode nd = nodes[q];
+                nodes[q].parent = prev;
+                nodes[q].flow = pf;
+                prev = q;
+                pf = nd.flow;
+                q = nd.parent;
+              }
+              nodes[x].parent = i;
+              nodes[x].flow = delta;
+              y = i;
+            }
+            double left = dem[sink] - delta;
+            if (left <= tol) {
+              left = 0.0;
+              dset[sink >> 5] &= ~(1u << (sink & 31));
+            }
+            dem[sink] = left;
+          }
+          __syncthreads();
+        }
+        EMD_MARK(4);
+        if (ctl[0] != 0) {
+          stop = true;
+          break;
+        }
+        ++n_aug;
+        r -= dctl[0];
+        // ---- labels of the trees on the path (their old roots carry a tag of this augmentation).  No arc cut: they
+        // have all become part of the source row's tree.  Otherwise every node of them starts from its parent and
+        // jumps three ancestors up per round until all of them name a root -------------------------------------------
+        {
+          const int t0 = tick;
+          tick = ctl[1];
+          const bool cut = ctl[8] != 0;
+          const int K0 = comp[i0];
+          unsigned aff = 0;
+          int q = 0;
+          for (int k = tid; k < N; k += T, ++q) {
+            if (nodes[comp[k]].stamp > t0) {
+              aff |= 1u << q;
+              if (cut) {
+                const int p = nodes[k].parent;
+                comp[k] = p >= 0 ? p : k;  // (nobody else reads comp[k] in this pass)
+              }
+            }
+          }
+          if (tid == 0) ctl[4] = 0;
+          __syncthreads();
+          if (!cut) {
+            q = 0;
+            for (int k = tid; k < N; k += T, ++q)
+              if ((aff >> q) & 1u) comp[k] = K0;
+            __syncthreads();
+          } else {
+            for (int round = 0; round < 40; ++round) {  // the depth shrinks fourfold per round
+              int changed = 0;
+              q = 0;
+              for (int k = tid; k < N; k += T, ++q) {
+                if ((aff >> q) & 1u) {
+                  const int c1 = comp[k];
+                  const int c2 = comp[c1];
+                  const int c3 = comp[c2];
+                  const int c4 = comp[c3];
+                  if (c4 != c1) {
+                    comp[k] = c4;
+                    changed = 1;
+                  }
+                }
+              }
+              if (changed) ctl[4 + round % 3] = 1;
+              if (tid == 0) ctl[4 + (round + 1) % 3] = 0;
+              __syncthreads();
+              if (!ctl[4 + round % 3]) break;
+            }
+          }
+        }
+        EMD_MARK(5);
+      }
+    }
+  }
+
+  // ---- emit the plan column by column (CSC, rows ascending inside a column) and the duals ------------------------
+  __syncthreads();
+  int err = ctl[0];
+  if (budget < 0 && err == 0) err = NIF_ERR_UNSUPPORTED;
+  if (lane == 0) atomicAdd(&ctl[2], n_rel);
+  for (int j = tid; j < n1; j += T) {
+    vg[j] = vl[j];
+    pred_row[j] = 0;
+  }
+  __syncthreads();
+  for (int k = tid; k < N; k += T) {
+    const int p = nodes[k].parent;
+    if (p >= 0) atomicAdd(&pred_row[(k < n0 ? p : k) - n0], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int j = 0; j < n1; ++j) {
+      const int cnt = pred_row[j];
+      colptr[j] = run;
+      entry[j] = run;  // write cursor of the column
+      run += cnt;
+    }
+    colptr[n1] = run;
+    if (err == 0 && run > out_cap) err = NIF_ERR_WORKSPACE;
+    status[0] = err != 0 ? err : run;
+    status[1] = n_aug;  // work counters: augmentations, Dijkstra steps, rows relaxed
+    status[2] = step;
+    status[3] = ctl[2];
+#ifdef NIF_EMD_TIMING
+    for (int q = 0; q < 6; ++q) status[4 + q] = (int)tk[q];
+    status[10] = (int)tk[6];
+    status[11] = (int)tk[7];
+    for (int q = 0; q < 3; ++q) status[12 + q] = hops[q];
+#endif
+    ctl[0] = err;
+  }
+  __syncthreads();
+  if (ctl[0] != 0) return;
+  for (int k = tid; k < N; k += T) {
+    const EmdNode nd = nodes[k];
+    if (nd.parent < 0) continue;
+    const int row = k < n0 ? k : nd.parent, col = (k < n0 ? nd.parent : k) - n0;
+    const int at = atomicAdd(&entry[col], 1);
+    rowidx[at] = row;
+    val[at] = nd.flow;
+  }
+  __syncthreads();
+  for (int j = tid; j < n1; j += T) {  // insertion sort of the column's few arcs by row: the same plan on every run
+    const int lo = colptr[j], hi = lo + pred_row[j];
+    for (int p = lo + 1; p < hi; ++p) {
+      const int rr = rowidx[p];
+      const double vv = val[p];
+      int q = p - 1;
+      for (; q >= lo && rowidx[q] > rr; --q) {
+        rowidx[q + 1] = rowidx[q];
+        val[q + 1] = val[q];
+      }
+      rowidx[q + 1] = rr;
+      val[q + 1] = vv;
+    }
+  }
+}
+
+template <int CPL, int NW, bool BIG>
+static void launch_emd_tree_v(const EmdTreeLds& L, hipStream_t st, const float* C, int64_t ldc, int n0, int n1,
+                              const double* a, const double* b, double tol, double* u, double* v, unsigned char* base,
+                              const EmdWs& w, int one_lane, int out_cap, int* colptr, int* rowidx, double* val,
+                              int* status) {
+  auto kfn = emd_tree_kernel<CPL, NW, BIG>;
+  static PerDeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+  });
+  hipLaunchKernelGGL(kfn, dim3(1), dim3(NW * 64), L.bytes, st, C, ldc, n0, n1, a, b, tol, u, v,
+                     reinterpret_cast<const int*>(base + w.off_jbest), reinterpret_cast<double*>(base + w.off_dem),
+                     reinterpret_cast<double*>(base + w.off_sup), reinterpret_cast<double*>(base + w.off_eflow),
+                     reinterpret_cast<int*>(base + w.off_arc), L, one_lane, out_cap, colptr, rowidx, val, status);
+}
+
+template <int CPL, int NW>
+static void launch_emd_tree(const EmdTreeLds& L, hipStream_t st, const float* C, int64_t ldc, int n0, int n1,
+                            const double* a, const double* b, double tol, double* u, double* v, unsigned char* base,
+                            const EmdWs& w, int one_lane, int out_cap, int* colptr, int* rowidx, double* val,
+                            int* status) {
+  if (L.big)
+    launch_emd_tree_v<CPL, NW, true>(L, st, C, ldc, n0, n1, a, b, tol, u, v, base, w, one_lane, out_cap, colptr, rowidx,
+                                     val, status);
+  else
+    launch_emd_tree_v<CPL, NW, false>(L, st, C, ldc, n0, n1, a, b, tol, u, v, base, w, one_lane, out_cap, colptr,
+                                      rowidx, val, status);
 }
 
 // out[j][q*sp + s] = beta * W0[j][q*sp + s]
@@ -634,6 +1414,27 @@ extern "C" int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, co
     hipLaunchKernelGGL(emd_colmin_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, C, ldc, n0, n1, vv);
     hipLaunchKernelGGL(emd_rowmin_kernel, dim3((n0 + 3) / 4), dim3(256), 0, st, C, ldc, n0, n1, vv, uu,
                        reinterpret_cast<int*>(base + w.off_jbest));
+  }
+  // the forest solver wherever its register and LDS plan fits (NIF_EMD_LEGACY / NIF_EMD_ARC_POOL: the arc-pool kernel)
+  static const int legacy = env_int("NIF_EMD_LEGACY");
+  if (!legacy && !(flags & (NIF_EMD_ARC_POOL | NIF_EMD_EDGES_GLOBAL)) && n1 <= 2048 &&
+      (size_t)w.cap * sizeof(double) >= (size_t)(n0 + n1) * sizeof(double)) {
+    const int cpl = (n1 + 63) / 64;
+    const int cplp = cpl <= 2 ? 2 : cpl <= 4 ? 4 : cpl <= 8 ? 8 : cpl <= 16 ? 16 : 32;
+    EmdTreeLds TL = emd_tree_lds(n0, n1, cplp, false);
+    if (TL.bytes > 158 * 1024) TL = emd_tree_lds(n0, n1, cplp, true);
+    if (TL.bytes <= 158 * 1024 && ((uint64_t)(n0 - 1) * (uint64_t)ldc + (uint64_t)n1) * 4 < 0xffffffffull) {
+#define NIF_EMD_TREE(CPL, NW)                                                                                          \
+  launch_emd_tree<CPL, NW>(TL, st, C, ldc, n0, n1, a, b, tol, uu, vv, base, w, (flags & NIF_EMD_ONE_LANE_PATHS) ? 1 : 0,   \
+                           out_cap, colptr, rowidx, val, status)
+      if (cpl <= 2) NIF_EMD_TREE(2, 8);
+      else if (cpl <= 4) NIF_EMD_TREE(4, 8);
+      else if (cpl <= 8) NIF_EMD_TREE(8, 8);
+      else if (cpl <= 16) NIF_EMD_TREE(16, 8);
+      else NIF_EMD_TREE(32, 4);
+#undef NIF_EMD_TREE
+      return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+    }
   }
   int cpt = 1;
   while (cpt < 8 && (n1 + cpt - 1) / cpt > 1024) cpt *= 2;

@@ -919,7 +919,7 @@ def _emd_problem(C, a, b):
                     colptr=torch.empty(n1 + 1, dtype=torch.int32, device=dev),
                     rowidx=torch.empty(cap, dtype=torch.int32, device=dev),
                     val=torch.empty(cap, dtype=torch.float64, device=dev),
-                    status=torch.zeros(4, dtype=torch.int32, device=dev),
+                    status=torch.zeros(16, dtype=torch.int32, device=dev),  # [4..] only a -DNIF_EMD_TIMING build writes
                     u=torch.empty(n0, dtype=torch.float64, device=dev),
                     v=torch.empty(n1, dtype=torch.float64, device=dev),
                     ws=torch.empty(wsz, dtype=torch.uint8, device=dev))
@@ -939,18 +939,20 @@ def _emd_result(p, work, duals):
     return (plan, p['u'], p['v']) if duals else plan
 
 
-def emd_solve(C, a, b, duals=False):
+def emd_solve(C, a, b, duals=False, flags=0):
     """Exact optimal transport plan for cost C (n0 x n1 f32, >= 0) and marginals a, b (``ot.emd(a, b, C)``,
-    otfusion.py:32).  b is rescaled to a's total like POT does.  Returns a SparsePlan (and f64 duals u, v)."""
+    otfusion.py:32).  b is rescaled to a's total like POT does.  Returns a SparsePlan (and f64 duals u, v).
+    flags: NIF_EMD_* tuning flags (cold start, the arc-pool kernel)."""
     p = _emd_problem(C, a, b)
     p['tol'] = float(p['tol'])
     with torch.cuda.device(p['dev']):
-        for flags in (0, _lib.NIF_EMD_EDGES_GLOBAL):
-            _emd_launch(p, flags, _stream())
+        for more in (0, _lib.NIF_EMD_EDGES_GLOBAL):
+            _emd_launch(p, flags | more, _stream())
             work = p['status'].tolist()
             if work[0] != _lib.NIF_ERR_WORKSPACE:  # a degenerate problem outgrew the LDS arc pool: retry once
                 break
     emd_solve.last_work = dict(augmentations=work[1], steps=work[2], rows_expanded=work[3])
+    emd_solve.last_status = work
     return _emd_result(p, work, duals)
 
 

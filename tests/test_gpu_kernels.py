@@ -412,6 +412,42 @@ def test_emd_optimality_certificate(ops, n0, n1):
     assert plan.nnz <= n0 + n1 - 1
 
 
+@pytest.mark.parametrize('n0,n1', [(1, 1), (3, 70), (64, 64), (130, 90), (257, 129), (384, 384), (640, 1000), (900, 2048),
+                                   (300, 2500)])
+def test_emd_kernels_agree(ops, n0, n1):
+    """The rooted-forest kernel (default where it fits: n1 <= 2048), the same with every augmenting path walked by its
+    general one-lane code, and the first-generation arc-pool kernel, from the cold and from the assignment start: each
+    passes the optimality certificate and all reach the same optimal value."""
+    from neuron_interpolation_model_fusion_amd import _lib
+    g = torch.Generator().manual_seed(n0 * 17 + n1)
+    C = torch.cdist(torch.randn(n0, 6, generator=g), torch.randn(n1, 6, generator=g))
+    a = torch.rand(n0, generator=g) ** 3 + 0.01   # skewed masses: many arcs run empty, trees are cut all the time
+    b = torch.rand(n1, generator=g) ** 3 + 0.01
+    a, b = a / a.sum(), b / b.sum()
+    vals = []
+    for flags in (0, _lib.NIF_EMD_ONE_LANE_PATHS, _lib.NIF_EMD_ARC_POOL, _lib.NIF_EMD_COLD_START,
+                  _lib.NIF_EMD_COLD_START | _lib.NIF_EMD_ONE_LANE_PATHS):
+        plan, u, v = ops.emd_solve(C.cuda(), a.cuda(), b.cuda(), duals=True, flags=flags)
+        vals.append(_check_transport_certificate(C, a, b, plan, u, v))
+        assert plan.nnz <= n0 + n1 - 1
+        # CSC with ascending rows inside a column
+        cp, ri = plan.colptr.cpu().numpy(), plan.rowidx.cpu().numpy()
+        assert cp[0] == 0 and cp[-1] == plan.nnz and (np.diff(cp) >= 0).all()
+    np.testing.assert_allclose(vals, vals[0], rtol=1e-12)
+
+
+def test_emd_forest_kernel_is_deterministic(ops):
+    g = torch.Generator().manual_seed(11)
+    C = torch.randint(0, 6, (200, 200), generator=g).float()   # integer costs: ties everywhere
+    a = torch.rand(200, generator=g) + 0.05
+    b = torch.rand(200, generator=g) + 0.05
+    runs = [ops.emd_solve(C.cuda(), (a / a.sum()).cuda(), (b / b.sum()).cuda(), duals=True) for _ in range(3)]
+    for plan, u, v in runs[1:]:
+        assert torch.equal(plan.colptr, runs[0][0].colptr) and torch.equal(plan.rowidx, runs[0][0].rowidx)
+        assert torch.equal(plan.val, runs[0][0].val) and torch.equal(u, runs[0][1]) and torch.equal(v, runs[0][2])
+    _check_transport_certificate(C, a / a.sum(), b / b.sum(), *runs[0])
+
+
 @pytest.mark.parametrize('n0,n1', [(6, 6), (12, 20), (60, 45), (150, 200)])
 def test_emd_plan_matches_the_lp_oracle(ops, n0, n1):
     from oracle import otfusion as o

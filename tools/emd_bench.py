@@ -4,17 +4,30 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuron_interpolation_model_fusion_amd import ops
 
+from neuron_interpolation_model_fusion_amd import _lib
+
+def check(C, a, b, plan, u, v):
+    """marginals met, duals feasible, complementary slackness (relative to the cost scale)"""
+    T = plan.dense(torch.float64)
+    a = a.double(); b = b.double() * (a.sum() / b.double().sum())
+    red = C.double() - u[:, None] - v[None, :]
+    scale = float(C.abs().max())
+    return (f'marg {float((T.sum(1) - a).abs().max() + (T.sum(0) - b).abs().max()):.1e} '
+            f'minred {float(red.min()) / scale:.1e} slack {float((red * (T > 0)).abs().max()) / scale:.1e}')
+
 def run(tag, C, a, b):
-    for cold in (('1', '0') if C.shape[0] == C.shape[1] else ('0',)):
-        os.environ['NIF_EMD_COLD_START'] = cold   # 1: column / row minimum start; 0: from the assignment solution (square)
-        ops.emd_solve(C, a, b); torch.cuda.synchronize()
-        t0 = time.perf_counter(); plan = ops.emd_solve(C, a, b); torch.cuda.synchronize()
+    variants = [('forest warm', 0), ('forest cold', _lib.NIF_EMD_COLD_START), ('pool warm', _lib.NIF_EMD_ARC_POOL),
+                ('pool cold', _lib.NIF_EMD_ARC_POOL | _lib.NIF_EMD_COLD_START)]
+    if C.shape[0] != C.shape[1]:
+        variants = [('forest', 0), ('pool', _lib.NIF_EMD_ARC_POOL)]
+    for name, flags in variants:
+        ops.emd_solve(C, a, b, flags=flags); torch.cuda.synchronize()
+        t0 = time.perf_counter(); plan, u, v = ops.emd_solve(C, a, b, duals=True, flags=flags); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         w = ops.emd_solve.last_work
         cost = float((plan.dense(torch.float64) * C.double()).sum())
-        print(f'{tag} [{"cold" if cold == "1" else "warm"}]: {C.shape[0]}x{C.shape[1]} {dt*1e3:.1f} ms, nnz {plan.nnz}, {w}, '
-              f'{dt*1e6/max(w["steps"],1):.2f} us/step, cost {cost:.9f}', flush=True)
-    os.environ.pop('NIF_EMD_COLD_START', None)
+        print(f'{tag} [{name}]: {C.shape[0]}x{C.shape[1]} {dt*1e3:.1f} ms, nnz {plan.nnz}, {w}, cost {cost:.9f}, '
+              f'{check(C, a, b, plan, u, v)}', flush=True)
 
 g = torch.Generator(device='cuda').manual_seed(0)
 for n0, n1 in ((384, 384), (512, 512), (1024, 1024), (2100, 1500)):
