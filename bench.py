@@ -351,6 +351,27 @@ def main():
         hard = {'levels_per_s': args.hard_steps / th, 'ms_per_step': th / args.hard_steps * 1e3, 'steps': args.hard_steps,
                 'lap_kernel_ms': lap_ms / max(lap_n, 1),
                 'instance': 'act_k ~ N(0,1) independent of act_f (no planted matching), serial loop'}
+        if overlap:
+            # the same levels through the loop the headline figure uses (Gram of level i + 1 on the front stream while
+            # the single-workgroup assignment of level i runs on the back stream)
+            # (measured: no gain -- 348 against 355 levels/s serial, 368 with eight CUs masked out of the Gram's stream so
+            # that a CU is always free.  profiles/r3_j_overlap_timeline.txt: side by side with Gram launches the
+            # single-workgroup search kernel takes 4.4 ms instead of 1.2 -- its dependent L2 round trips queue behind
+            # the Gram's traffic -- and the dual initialisation's blocks wait 0.6 ms for CUs)
+            piph = LevelPipeline(ops, lvh, None)
+            piph.run(2)
+            torch.cuda.synchronize()
+            ops.profile_collect(ops.PROF_LAP)
+            ops.profile_enable(True, slots=[ops.PROF_LAP])
+            tp = time.perf_counter()
+            piph.run(args.hard_steps)
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - tp
+            ops.profile_enable(False)
+            lap_ms, lap_n = ops.profile_collect(ops.PROF_LAP)
+            hard['pipelined_levels_per_s'] = args.hard_steps / tp
+            hard['pipelined_ms_per_step'] = tp / args.hard_steps * 1e3
+            hard['pipelined_lap_kernel_ms'] = lap_ms / max(lap_n, 1)
         del lvh
 
     # Third figure (N = 1): the same level with the ADDITIONAL Sinkhorn solver in place of the exact assignment
