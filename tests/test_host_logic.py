@@ -254,3 +254,31 @@ def test_alf_flatten_and_join_equals_flatten_normalise_concatenate():
         assert torch.equal(joined, want) and torch.equal(normed, want_n)
         joined2, same = ALFusion._flatten_and_join(None, acts, False)
         assert same is joined2 and torch.equal(joined2, want)
+
+
+def test_duplicate_line_filter_of_the_scipy_order_assignment():
+    """ops._has_duplicate_lines (the cheap test that spares a fast solve whose certificate would fail): identical rows or
+    identical columns are found wherever they sit; matrices without them -- also ones whose lines share a sum -- pass."""
+    from neuron_interpolation_model_fusion_amd import ops
+    g = torch.Generator().manual_seed(3)
+    C = torch.rand(40, 40, generator=g)
+    assert not bool(ops._has_duplicate_lines(C))
+    D = C.clone()
+    D[31] = D[4]
+    assert bool(ops._has_duplicate_lines(D))
+    D = C.clone()
+    D[:, 0] = D[:, 39]
+    assert bool(ops._has_duplicate_lines(D))
+    # equal sums, different maxima: not a duplicate (a false alarm would only cost the slower replay kernel)
+    E = torch.randint(100, 1000, (40, 40), generator=g).float()   # integers: the sums are exact
+    E[7] = E[9]
+    k = int(E[9].argmax())
+    E[7, k] += 8.0
+    E[7, (k + 1) % 40] -= 8.0
+    assert float(E[7].double().sum()) == float(E[9].double().sum())
+    assert not bool(ops._has_duplicate_lines(E))
+    # dead units of a random-initialised network: all-zero activations give identical cost lines
+    Z = C.clone()
+    Z[:, 5] = 1.5
+    Z[:, 17] = 1.5
+    assert bool(ops._has_duplicate_lines(Z))
