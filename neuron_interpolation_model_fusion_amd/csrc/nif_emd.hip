@@ -770,6 +770,12 @@ __global__ __launch_bounds__(NW * 64) void emd_tree_kernel(const float* __restri
           pred[c] = -1;
           if ((dset[2 * c + (lane >> 5)] >> (lane & 31)) & 1u) defm |= 1u << c;  // column lane + 64 c
         }
+        if (tick > (1 << 30)) {  // (uniform) the tags would wrap: start them over
+          __syncthreads();
+          for (int k = tid; k < N; k += T) nodes[k].stamp = 0;
+          tick = 0;
+          __syncthreads();
+        }
         const int s = ++tick;
         int K = comp[i0], e = i0, sink = -1;
         double D = 0.0;
