@@ -77,12 +77,12 @@ def level_front(ops, lv, dist=None):
     G, na, nb = ops.xty(lv['act_k'], lv['act_f'], acc='f32', split_bf16=lv.get('split_bf16', False),
                         out=unpack_gram(buf, n0, n1))
     # ordinary stream-ordered collective on the front stream: RCCL runs it on its own stream and the front
-    # stream waits for it, so it overlaps with the back half of the previous level on the other stream
-    if lv.get('host_sync_before_collective'):
-        # gloo rehearsal only (two ranks time-slicing one GPU): gloo's device path waits for the tensor on its own
-        # side stream, which stalled behind the peer's queued kernels; a host sync first keeps it to plain copies
-        torch.cuda.synchronize()
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    # stream waits for it, so it overlaps with the back half of the previous level on the other stream.  The gloo
+    # rehearsal (two ranks time-slicing one GPU) goes through the library's own wrapper instead, i.e. a host copy:
+    # gloo's device path stalled between the ranks again this round (--overlap-multi: both ranks inside all_reduce until
+    # the watchdog), the host synchronisation in front of it notwithstanding
+    from neuron_interpolation_model_fusion_amd.parallel import all_reduce_sum
+    all_reduce_sum(buf)
     return G, na, nb, buf, None
 
 
@@ -197,19 +197,30 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1 and args.backend != 'nccl':
+        # gloo rehearsal (ranks share a GPU): the process group first -- it needs no GPU -- and then the GPU brought up
+        # rank by rank: two processes initialising a fresh GPU at the same moment have stalled for minutes on this pool
+        # (the first attempt of this round's rehearsal sat 3 minutes before its first level; the next one took 5 s)
+        import torch.distributed as dist
+        dist.init_process_group(args.backend)
+        for r in range(world):
+            if r == rank:
+                torch.zeros(1, device=f'cuda:{local_rank % max(torch.cuda.device_count(), 1)}')
+                torch.cuda.synchronize()
+            dist.barrier()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback for the product path)')
     local_rank %= torch.cuda.device_count()  # ranks share a GPU only in the gloo rehearsal
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    dist = None
     # NIF_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, packed all-reduce per level on the front stream,
     # barrier, max over ranks) with a single rank too -- the way to run the RCCL path on a one-GPU box
     force_dist = world == 1 and os.environ.get('NIF_BENCH_FORCE_DIST') == '1'
     if force_dist:
         for key, val in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29533'), ('RANK', '0'), ('WORLD_SIZE', '1')):
             os.environ.setdefault(key, val)
-    if world > 1 or force_dist:
+    if (world > 1 or force_dist) and dist is None:
         import torch.distributed as dist
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
@@ -282,6 +293,10 @@ def main():
                 marks.append(ev_done)
         return res
 
+    # control scalars of the collectives (go / no-go of the pre-heat, the max over ranks): device tensors for RCCL, host
+    # tensors for the gloo rehearsal -- gloo's device path stalls between ranks that share a GPU (both ranks of this
+    # round's rehearsal sat in dist.broadcast of a device scalar until the watchdog ended them)
+    ctl_device = device if args.backend == 'nccl' else torch.device('cpu')
     # Pre-heat: the same loop for a fixed wall time before anything is counted, whatever --warmup says.  A cold GPU
     # (idle clocks, code objects not yet resident, allocator empty) gave 0.815 ms per Gram launch over 5 + 20 levels
     # where 2000 levels average 0.728 ms; `warmup` stays the flag's count of untimed levels and runs after this.
@@ -290,7 +305,7 @@ def main():
     preheat_levels = 0
     while True:
         # every rank must run the same number of collectives: rank 0's clock decides
-        go = torch.tensor([1.0 if time.perf_counter() - t_pre < preheat_s else 0.0], device=device)
+        go = torch.tensor([1.0 if time.perf_counter() - t_pre < preheat_s else 0.0], device=ctl_device)
         if dist is not None:
             dist.broadcast(go, src=0)
         if float(go.item()) == 0.0:
@@ -324,7 +339,7 @@ def main():
         ys = sorted(xs)
         return {'min': ys[0], 'median': ys[len(ys) // 2], 'max': ys[-1], 'mean': sum(ys) / len(ys), 'n': len(ys)}
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=ctl_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
