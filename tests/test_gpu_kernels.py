@@ -413,7 +413,7 @@ def test_emd_optimality_certificate(ops, n0, n1):
 
 
 @pytest.mark.parametrize('n0,n1', [(1, 1), (3, 70), (64, 64), (130, 90), (257, 129), (384, 384), (640, 1000), (900, 2048),
-                                   (300, 2500)])
+                                   (300, 2500), (2300, 2000)])   # the last: the forest kernel with its per-tree distances and demands in the workspace
 def test_emd_kernels_agree(ops, n0, n1):
     """The rooted-forest kernel (default where it fits: n1 <= 2048), the same with every augmenting path walked by its
     general one-lane code, and the first-generation arc-pool kernel, from the cold and from the assignment start: each
