@@ -252,6 +252,166 @@ __global__ __launch_bounds__(256) void sk_rowpass_kernel(const float* __restrict
   if (mybad) atomicOr(&ctl[3], 1);  // rare; the next kernel that looks freezes the state one iteration back
 }
 
+// ---- small problems: every iteration inside ONE workgroup ----------------------------------------------------------
+// Three launches per iteration are 13-15 us whatever the size, and below n ~ 1024 that is all an iteration costs.  Up to
+// n ~ 192 one workgroup of 1024 lanes is quicker than that and runs the whole loop (measured, tools/sinkhorn_bench.py,
+// us per iteration, one workgroup / three launches: n = 64 5.7 / 13.1, 128 7.6 / 13.3, 192 10.6 / 13.2; from n = 256 on
+// one CU's loads are the slower side -- 13.5 / 13.2, 384: 25 / 14.5 -- and the launches stay): column pass (a lane owns four columns and every nsl-th row, partial sums combined
+// in slice order), error test / v = b / s, row pass (a wave owns blocks of four rows), u = a / t, with u and v in LDS and
+// the same test schedule, freeze and breakdown rules as the three kernels above; no host look between batches.  The
+// final state goes where sk_plan_kernel expects it.
+constexpr int SK_SMALL_MAX_ELEMS = 192 * 192;
+
+__global__ __launch_bounds__(1024) void sk_small_kernel(const float* __restrict__ K, int64_t ldk, int n0, int n1,
+                                                        const double* __restrict__ a, const double* __restrict__ b,
+                                                        int max_iter, int check_every, double tol,
+                                                        double* __restrict__ ubuf, double* __restrict__ vbuf,
+                                                        int* __restrict__ ctl, double* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sk_sm[];
+  const int Q = (n1 + 3) / 4;          // column quads
+  const int nsl = 1024 / Q;            // row slices of the column pass (>= 4: n1 <= 1024)
+  const int n1p = 4 * Q;
+  double* su = reinterpret_cast<double*>(sk_sm);  // [2][n0]
+  double* sv = su + 2 * n0;                        // [2][n1p]
+  double* part = sv + 2 * n1p;                     // [nsl][n1p]
+  double* red = part + (size_t)nsl * n1p;          // [16] + [1]
+  int* flags = reinterpret_cast<int*>(red + 20);   // 0: bad column sum, 1: bad row sum
+  double* sa = red + 22;                           // [n0] the marginals, read every iteration
+  double* sb = sa + n0;                            // [n1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int i = tid; i < n0; i += 1024) {
+    su[i] = ubuf[i];
+    sa[i] = a[i];
+  }
+  for (int j = tid; j < n1p; j += 1024) sv[j] = j < n1 ? vbuf[j] : 0.0;
+  for (int j = tid; j < n1; j += 1024) sb[j] = b[j];
+  if (tid < 2) flags[tid] = 0;
+  __syncthreads();
+
+  const int cq = tid % Q, slice = tid / Q;
+  int state = 0, completed = max_iter, cur = 0;
+  double last_err = INFINITY;
+  for (int q = 0; q < max_iter; ++q) {
+    cur = q & 1;
+    const double* __restrict__ u = su + (size_t)cur * n0;
+    const double* __restrict__ v = sv + (size_t)cur * n1p;
+    double* __restrict__ un = su + (size_t)(cur ^ 1) * n0;
+    double* __restrict__ vn = sv + (size_t)(cur ^ 1) * n1p;
+    // column pass
+    if (slice < nsl) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      const float* __restrict__ col = K + 4 * cq;
+      int i = slice;
+      for (; i + 7 * nsl < n0; i += 8 * nsl) {  // eight rows in flight
+        float4 k4[8];
+        double ui[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          k4[r] = *reinterpret_cast<const float4*>(col + (int64_t)(i + r * nsl) * ldk);
+          ui[r] = u[i + r * nsl];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          acc[0] += ui[r] * (double)k4[r].x;
+          acc[1] += ui[r] * (double)k4[r].y;
+          acc[2] += ui[r] * (double)k4[r].z;
+          acc[3] += ui[r] * (double)k4[r].w;
+        }
+      }
+      for (; i < n0; i += nsl) {
+        const float4 k4 = *reinterpret_cast<const float4*>(col + (int64_t)i * ldk);
+        const double ui = u[i];
+        acc[0] += ui * (double)k4.x;
+        acc[1] += ui * (double)k4.y;
+        acc[2] += ui * (double)k4.z;
+        acc[3] += ui * (double)k4.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[(size_t)slice * n1p + 4 * cq + e] = acc[e];
+    }
+    __syncthreads();
+    // POT tests after the iterations with ii % 10 == 0, i.e. after 1, 11, 21, ... completed iterations
+    const bool check = q > 0 && ((q - 1) % check_every == 0);
+    double e2 = 0.0;
+    for (int j = tid; j < n1; j += 1024) {
+      double sj = 0.0;
+      for (int sl = 0; sl < nsl; ++sl) sj += part[(size_t)sl * n1p + j];
+      if (check) {
+        const double d = v[j] * sj - sb[j];
+        e2 += d * d;
+      }
+      const double nv = sb[j] / sj;
+      if (sj == 0.0 || !isfinite(nv)) flags[0] = 1;
+      vn[j] = nv;
+    }
+    if (check) {  // uniform
+      e2 = wave_sum_f64(e2);
+      if (lane == 0) red[wave] = e2;
+    }
+    __syncthreads();
+    if (check) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) tot += red[w];
+      last_err = sqrt(tot);
+      if (last_err < tol) state = 1;
+    }
+    if (state == 0 && flags[0]) state = 2;
+    if (state != 0) {  // frozen: the result is the state this iteration started from
+      completed = q;
+      break;
+    }
+    // row pass: blocks of four rows per wave
+    for (int g = wave; 4 * g < n0; g += 16) {
+      const int i0 = 4 * g;
+      const float* __restrict__ rows[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rows[r] = K + (int64_t)min(i0 + r, n0 - 1) * ldk;  // clamped rows are dropped below
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int j4 = lane; j4 < Q; j4 += 64) {
+        float4 k4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) k4[r] = *reinterpret_cast<const float4*>(rows[r] + 4 * j4);
+        const double2 v01 = *reinterpret_cast<const double2*>(vn + 4 * j4);
+        const double2 v23 = *reinterpret_cast<const double2*>(vn + 4 * j4 + 2);
+        // (columns beyond n1 inside the last quad: K's pad may hold anything, so they are masked, not multiplied by 0)
+        const bool f1 = 4 * j4 + 1 < n1, f2 = 4 * j4 + 2 < n1, f3 = 4 * j4 + 3 < n1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[r] += ((double)k4[r].x * v01.x + (f1 ? (double)k4[r].y * v01.y : 0.0)) +
+                    ((f2 ? (double)k4[r].z * v23.x : 0.0) + (f3 ? (double)k4[r].w * v23.y : 0.0));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double t = wave_sum_f64(acc[r]);
+        if (lane == 0 && i0 + r < n0) {
+          const double nu = sa[i0 + r] / t;
+          un[i0 + r] = nu;
+          if (t == 0.0 || !isfinite(nu)) flags[1] = 1;
+        }
+      }
+    }
+    __syncthreads();
+    if (flags[1]) {  // the row pass broke down: its inputs are the result (POT keeps uprev, vprev)
+      state = 2;
+      completed = q;
+      break;
+    }
+  }
+  if (state == 0) cur = max_iter & 1;  // all iterations ran: the buffers written last
+  __syncthreads();
+  for (int i = tid; i < n0; i += 1024) ubuf[(size_t)cur * n0 + i] = su[(size_t)cur * n0 + i];
+  for (int j = tid; j < n1; j += 1024) vbuf[(size_t)cur * n1 + j] = sv[(size_t)cur * n1p + j];
+  if (tid == 0) {
+    ctl[0] = state;
+    ctl[1] = completed;
+    ctl[2] = cur;
+    ctl[3] = 0;
+    if (last_err < INFINITY) *err = last_err;
+  }
+}
+
 // T[i][j] = u_i K[i][j] v_j with the current buffers; also copies u, v out
 __global__ void sk_plan_kernel(const float* __restrict__ K, int64_t ldk, int n0, int n1,
                                const double* __restrict__ ubuf, const double* __restrict__ vbuf,
@@ -318,6 +478,25 @@ extern "C" int nif_sinkhorn_f32(const float* C, int64_t ldc, int n0, int n1, con
   const int64_t cover = total > n0 ? (total > n1 ? total : n1) : (n0 > n1 ? n0 : n1);
   const unsigned eb = (unsigned)((cover + 255) / 256);
   hipLaunchKernelGGL(sk_init_kernel, dim3(eb), dim3(256), 0, st, C, ldc, n0, n1, reg, K, ldk, ubuf, vbuf, ctl, err);
+  // small problems: the whole loop in one workgroup (NIF_SINKHORN_LAUNCHES=1 keeps the three launches per iteration)
+  static const int sk_launches = env_int("NIF_SINKHORN_LAUNCHES");
+  if (!sk_launches && n1 <= 1024 && n0 <= 4096 && (int64_t)n0 * n1 <= SK_SMALL_MAX_ELEMS && max_iter > 0) {
+    const int Qh = (n1 + 3) / 4, nslh = 1024 / Qh, n1ph = 4 * Qh;
+    const size_t lds = ((size_t)3 * n0 + 2 * n1ph + (size_t)nslh * n1ph + 22 + n1) * sizeof(double);
+    static PerDeviceOnce attr_once;
+    attr_once.run([&] {
+      (void)hipFuncSetAttribute((const void*)sk_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    if (lds <= 128 * 1024) {
+      prof_begin(NIF_PROF_SINKHORN, st);
+      hipLaunchKernelGGL(sk_small_kernel, dim3(1), dim3(1024), lds, st, K, ldk, n0, n1, a, b, max_iter, 10, tol, ubuf, vbuf,
+                         ctl, err);
+      prof_end(NIF_PROF_SINKHORN, st);
+      hipLaunchKernelGGL(sk_plan_kernel, dim3((unsigned)((cover + 255) / 256)), dim3(256), 0, st, K, ldk, n0, n1, ubuf,
+                         vbuf, ctl, max_iter, T, ldt, u_out, v_out, info);
+      return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+    }
+  }
   const dim3 cgrid((n1 + SK_COLS - 1) / SK_COLS, w.chunks);
   const unsigned rgrid = (unsigned)((n0 + 3) / 4);
   // iterations are enqueued in batches; between batches the host reads the state word (the only synchronisations)

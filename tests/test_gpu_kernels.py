@@ -478,7 +478,8 @@ def test_emd_solve_many_equals_one_by_one(ops):
         assert torch.equal(plan.val, one.val) and torch.equal(u, u1) and torch.equal(v, v1)
 
 
-@pytest.mark.parametrize('n0,n1,reg', [(17, 17, 0.1), (64, 48, 0.05), (384, 384, 0.05), (300, 771, 0.08), (1024, 1024, 0.02)])
+@pytest.mark.parametrize('n0,n1,reg', [(17, 17, 0.1), (64, 48, 0.05), (150, 190, 0.06), (192, 192, 0.05), (384, 384, 0.05),
+                                        (300, 771, 0.08), (1024, 1024, 0.02)])   # up to 192 x 192: the one-workgroup kernel
 def test_sinkhorn_matches_the_f64_restatement(ops, n0, n1, reg):
     """The additional Sinkhorn mode against oracle.otfusion.sinkhorn_knopp (POT's algorithm restated, parity unpinned):
     same iteration count (the stopping rule is evaluated on the same iterations), plan and marginals."""
