@@ -436,6 +436,37 @@ def test_emd_kernels_agree(ops, n0, n1):
     np.testing.assert_allclose(vals, vals[0], rtol=1e-12)
 
 
+def test_emd_many_small_random_problems_reach_the_lp_value(ops):
+    """Forty small problems of every flavour the kernels branch on -- square / wide / tall, continuous and integer
+    (massively tied) costs, uniform, skewed and partly zero marginals -- through the forest kernel, its one-lane path
+    code and the arc-pool kernel: certificate each time, and the optimal value of the LP oracle (HiGHS)."""
+    from oracle import otfusion as o
+    from neuron_interpolation_model_fusion_amd import _lib
+    g = torch.Generator().manual_seed(2024)
+    for case in range(40):
+        n0 = int(torch.randint(1, 41, (1,), generator=g))
+        n1 = n0 if case % 3 == 0 else int(torch.randint(1, 41, (1,), generator=g))
+        if case % 4 == 1:
+            C = torch.randint(0, 5, (n0, n1), generator=g).float()
+        else:
+            C = torch.cdist(torch.randn(n0, 3, generator=g), torch.randn(n1, 3, generator=g))
+        if case % 5 == 2:
+            a, b = torch.full((n0,), 1.0 / n0), torch.full((n1,), 1.0 / n1)
+        else:
+            a = torch.rand(n0, generator=g) ** 4 + (0.0 if case % 5 == 3 else 0.01)
+            b = torch.rand(n1, generator=g) ** 4 + (0.0 if case % 5 == 3 else 0.01)
+            if case % 5 == 3 and n0 > 2 and n1 > 2:
+                a[::3] = 0.0
+                b[1::4] = 0.0
+            a, b = a / a.sum(), b / b.sum()
+        ref = o.emd(a.double().numpy(), b.double().numpy(), C.numpy())
+        ref_val = float((ref.double() * C.double()).sum())
+        for flags in (0, _lib.NIF_EMD_ONE_LANE_PATHS, _lib.NIF_EMD_ARC_POOL, _lib.NIF_EMD_COLD_START):
+            plan, u, v = ops.emd_solve(C.cuda(), a.cuda(), b.cuda(), duals=True, flags=flags)
+            val = _check_transport_certificate(C, a, b, plan, u, v)
+            np.testing.assert_allclose(val, ref_val, rtol=1e-6, atol=1e-9, err_msg=f'case {case} ({n0} x {n1}) flags {flags}')
+
+
 def test_emd_forest_kernel_is_deterministic(ops):
     g = torch.Generator().manual_seed(11)
     C = torch.randint(0, 6, (200, 200), generator=g).float()   # integer costs: ties everywhere
