@@ -326,7 +326,8 @@ int nif_refit_pairs(const double* W, int64_t ldw, const int32_t* col, const floa
 /* ---- exact optimal transport with arbitrary marginals (POT `ot.emd`, otfusion.py:18-32, call site :309) ----
  * min <T, C> s.t. T 1 = a, T^T 1 = b, T >= 0 for a dense n0 x n1 f32 cost (>= 0) and f64 marginals with equal
  * sums (POT rescales b to a's total; the caller does the same).  Successive shortest augmenting paths, f64
- * duals, one workgroup.  The plan comes back sparse, by column: colptr[n1 + 1], rowidx / val[<= out_cap]
+ * duals, one workgroup (the support kept as a rooted forest in LDS up to n1 = 2048, as an arc pool beyond; square
+ * problems start from the assignment solution of the same costs).  The plan comes back sparse, by column: colptr[n1 + 1], rowidx / val[<= out_cap]
  * (a vertex of the transport polytope has at most n0 + n1 - 1 positive entries).  status (device, 4 ints):
  * [0] = number of entries, or a negative NIF_ERR_*; [1..3] = work counters (augmentations, Dijkstra steps,
  * rows expanded).  tol: flows / supplies below it count as zero (e.g. 1e-13 * sum a).
