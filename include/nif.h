@@ -305,6 +305,26 @@ int nif_kmeans_repair_kf_batch(int32_t* assign, double* nearest, const float* s,
                                const int32_t* tries_idx, int n_tries, int32_t* changed, void* ws, size_t ws_bytes,
                                void* stream);
 
+/* The Lloyd step of a run whose ranks all hold the reduced Gram (the sample-sharded levels of hf_kf.py:420-475, f1):
+ * the pass over G that finds every neuron's nearest centroid is split by neuron.  This call does the whole step's
+ * O(N) part (grouping, cluster weights and norms) and the G pass for the 64-neuron blocks [blk_lo, blk_hi) only: it
+ * writes assign_out / nearest for the neurons 64 blk_lo .. min(N, 64 blk_hi) - 1 and partial[blk] (the blocks' shares
+ * of the cost; partial is [tries][ceil(N / 64)] f64, or one row when tries_idx is NULL) for those blocks, and leaves
+ * everything else of the three untouched.  The caller zeroes the three, sums them over the ranks (every entry has
+ * one writer, so the sum is exact) and forms the cost with nif_kmeans_cost_from_partials, which adds the partials in
+ * nif_kmeans_lloyd_step's order: a sharded step returns the bits of an unsharded one.  tries_idx / n_tries as in the
+ * batch calls (NULL: the single problem). */
+int nif_kmeans_lloyd_step_range(const double* G, int64_t ldg, const double* nn, const float* s, const int32_t* assign,
+                                int N, int k, const int32_t* tries_idx, int n_tries, int blk_lo, int blk_hi,
+                                int32_t* assign_out, double* nearest, double* partial, int32_t* kprime, void* ws,
+                                size_t ws_bytes, void* stream);
+int nif_kmeans_lloyd_step_range_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn, const float* s,
+                                     const int32_t* assign, int N, int k, const int32_t* tries_idx, int n_tries,
+                                     int blk_lo, int blk_hi, int32_t* assign_out, double* nearest, double* partial,
+                                     int32_t* kprime, void* ws, size_t ws_bytes, void* stream);
+int nif_kmeans_cost_from_partials(const double* partial, int nblocks, const int32_t* tries_idx, int n_tries,
+                                  double* cost, void* stream);
+
 /* Fused neurons from a clustering, hf_kf.py:283-312,494-504: out[cc][r] = sum_{i in c} s_i W[r][i] / S_c
  * for the non-empty clusters in label order (rows >= *kprime stay zero). W: d x N f64 (LS solutions
  * as columns), out: k x d f32. */

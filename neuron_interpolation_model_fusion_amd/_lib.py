@@ -67,6 +67,11 @@ SIGNATURES = {
     'nif_kmeans_lloyd_step_batch': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nif_kmeans_lloyd_step_batch_gf32': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz,
                                                 _vp]),
+    'nif_kmeans_lloyd_step_range': (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                                           _sz, _vp]),
+    'nif_kmeans_lloyd_step_range_gf32': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
+                                                _vp, _vp, _sz, _vp]),
+    'nif_kmeans_cost_from_partials': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp]),
     'nif_kmeans_repair_kf_batch': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     'nif_kmeans_repair_kf': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     'nif_kmeans_centroid_weights': (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -70,6 +70,7 @@ struct FiFirsts {
 struct KmBatch {
   int idx[FI_MAX_TRIES];
   long long ws_stride;
+  int blk0;  // first 64-neuron block of the launch (the two passes over G of a neuron-sharded Lloyd step); else 0
 };
 template <typename T>
 __device__ __forceinline__ T* kb_ws(T* p, const KmBatch& kb) {
@@ -560,6 +561,26 @@ __global__ __launch_bounds__(64) void kmeans_cost_kernel(const double* __restric
   if (threadIdx.x == 0) *cost = t;
 }
 
+// Neuron-sharded step: the partials of this rank's blocks leave the workspace as a slice of a [tries][nblocks] tensor
+// (the other entries are the other ranks'), and the cost is formed from the exchanged tensor in kmeans_cost_kernel's
+// order, so a sharded step returns the bits of an unsharded one.
+__global__ void kmeans_partial_export_kernel(const double* __restrict__ partial, int nblocks, int lo, int hi,
+                                             double* __restrict__ out, KmBatch kb) {
+  partial = kb_ws(partial, kb);
+  out = kb_row(out, kb, nblocks);
+  const int b = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < hi) out[b] = partial[b];
+}
+__global__ __launch_bounds__(64) void kmeans_cost_rows_kernel(const double* __restrict__ partial, int nblocks,
+                                                              double* __restrict__ cost, KmBatch kb) {
+  partial = kb_row(partial, kb, nblocks);
+  cost = kb_row(cost, kb, 1);
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) t += partial[b];
+  t = wave_sum_f64(t);
+  if (threadIdx.x == 0) *cost = t;
+}
+
 // ---- Lloyd step: H is never stored ---------------------------------------------------------------------------
 // H[c][j] = sum_{i in c} s_i G[i][j] / S_c (k x N) is needed for two things only: the k centroid norms, which use
 // H[c][i] for i INSIDE cluster c alone (sum of n_c^2 Gram entries, a sliver of G), and one running minimum per
@@ -597,7 +618,7 @@ __global__ __launch_bounds__(1024) void kmeans_bigtot_kernel(const GT* __restric
   __shared__ double part[16][64];
   const int tx = threadIdx.x & 63;
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = blockIdx.x * 64 + tx;
+  const int j = (kb.blk0 + (int)blockIdx.x) * 64 + tx;
   const int jc = j < N ? j : N - 1;
   const double gjj = sizeof(GT) == 4 ? gd[jc] : 0.0;
   const GT* __restrict__ col = G + jc;
@@ -777,7 +798,8 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
   __shared__ int cand_c[16][64];
   const int tx = threadIdx.x & 63;
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = blockIdx.x * 64 + tx;
+  const int blk = kb.blk0 + (int)blockIdx.x;
+  const int j = blk * 64 + tx;
   const int jc = j < N ? j : N - 1;  // lanes past the end compute a valid column and drop it
   const int per = (k + 15) / 16;
   const int c_lo = ty * per, c_hi = min(k, c_lo + per);
@@ -869,7 +891,7 @@ __global__ __launch_bounds__(1024) void kmeans_nearest_fused_kernel(
     contrib = (double)s[j] * d;
   }
   contrib = wave_sum_f64(contrib);
-  if (tx == 0) partial[blockIdx.x] = contrib;
+  if (tx == 0) partial[blk] = contrib;
 }
 
 // ---- KF empty-cluster repair (hf_kf.py:466-471), one workgroup --------------------------------------
@@ -1289,6 +1311,7 @@ static KmBatch km_single() {
   KmBatch kb;
   for (int t = 0; t < FI_MAX_TRIES; ++t) kb.idx[t] = 0;
   kb.ws_stride = 0;
+  kb.blk0 = 0;
   return kb;
 }
 
@@ -1459,10 +1482,23 @@ static int km_batch(const int32_t* tries_idx, int L, size_t stride, size_t ws_by
 template <typename GT>
 static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const double* nn, const float* s,
                          const int32_t* assign, int N, int k, const int32_t* tries_idx, int L, int32_t* assign_out,
-                         double* nearest, double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
-  if (!G || !nn || !s || !assign || !assign_out || !nearest || !cost || !kprime || N <= 0 || k <= 0 || ldg < N ||
-      (sizeof(GT) == 4 && !gd))
+                         double* nearest, double* cost, int32_t* kprime, void* ws, size_t ws_bytes, void* stream,
+                         int blk_lo = 0, int blk_hi = -1, double* partial_out = nullptr) {
+  // partial_out set: the neuron-sharded form.  Only the 64-neuron blocks [blk_lo, blk_hi) go through the two passes
+  // over G; their slices of assign_out / nearest / partial_out are written and `cost` is not (see
+  // nif_kmeans_lloyd_step_range in nif.h).  The grouping and the per-cluster kernels run in full on every rank: they
+  // read O(N) labels and the member-by-member sliver of G, not G.
+  const bool ranged = partial_out != nullptr;
+  if (!G || !nn || !s || !assign || !assign_out || !nearest || (!cost && !ranged) || !kprime || N <= 0 || k <= 0 ||
+      ldg < N || (sizeof(GT) == 4 && !gd))
     return NIF_ERR_INVALID_ARG;
+  const int nb64 = (N + 63) / 64;
+  if (!ranged) {
+    blk_lo = 0;
+    blk_hi = nb64;
+  } else if (blk_lo < 0 || blk_hi < blk_lo || blk_hi > nb64) {
+    return NIF_ERR_INVALID_ARG;
+  }
   const KmWs w = km_ws(N, k);
   if (!ws || ws_bytes < w.total) return NIF_ERR_WORKSPACE;
   KmBatch kb;
@@ -1479,7 +1515,6 @@ static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const doubl
   double* partial = reinterpret_cast<double*>(b + w.off_partial);
   double* hself = reinterpret_cast<double*>(b + w.off_hself);
   float* ssorted = reinterpret_cast<float*>(b + w.off_wsorted);
-  const int nb64 = (N + 63) / 64;
   km_group(assign, N, k, w, b, kprime, st, kb, L);
   hipLaunchKernelGGL(kmeans_S_kernel, dim3((k + 3) / 4, L), dim3(256), 0, st, s, order, seg, compact, k, S, kb);
   hipLaunchKernelGGL(kmeans_ssorted_kernel, dim3(w.nblk, L), dim3(256), 0, st, s, order, N, ssorted, kb);
@@ -1491,16 +1526,25 @@ static int km_lloyd_step(const GT* G, int64_t ldg, const double* gd, const doubl
   hipLaunchKernelGGL(kmeans_cn_self_kernel, dim3((k + 3) / 4, L), dim3(256), 0, st, hself, s, order, seg, compact, S, k, cn,
                      bigflag, kb);
   if (km_big_slots(N) > 0) {  // both leave at once when the step has no big cluster
+    // (a big cluster's norm needs its sums at its own members, which lie anywhere: this pass stays whole when sharded)
     hipLaunchKernelGGL(kmeans_bigtot_kernel<GT>, dim3(nb64, L), dim3(1024), 0, st, G, ldg, gd, ssorted, order, seg, biglist,
                        N, bigtot, kb);
     hipLaunchKernelGGL(kmeans_cn_big_kernel, dim3(km_big_slots(N), L), dim3(256), 0, st, bigtot, N, ssorted, order, seg,
                        compact, biglist, S, cn, kb);
   }
-  prof_begin(NIF_PROF_KMEANS, st);
-  hipLaunchKernelGGL(kmeans_nearest_fused_kernel<GT>, dim3(nb64, L), dim3(1024), 0, st, G, ldg, gd, ssorted, order, seg,
-                     compact, S, cn, nn, s, N, k, assign_out, nearest, partial, bigflag, biglist, bigtot, kb);
-  prof_end(NIF_PROF_KMEANS, st);
-  hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1, L), dim3(64), 0, st, partial, nb64, cost, kb);
+  if (blk_hi > blk_lo) {
+    KmBatch kr = kb;
+    kr.blk0 = blk_lo;
+    prof_begin(NIF_PROF_KMEANS, st);
+    hipLaunchKernelGGL(kmeans_nearest_fused_kernel<GT>, dim3(blk_hi - blk_lo, L), dim3(1024), 0, st, G, ldg, gd, ssorted,
+                       order, seg, compact, S, cn, nn, s, N, k, assign_out, nearest, partial, bigflag, biglist, bigtot, kr);
+    prof_end(NIF_PROF_KMEANS, st);
+  }
+  if (!ranged)
+    hipLaunchKernelGGL(kmeans_cost_kernel, dim3(1, L), dim3(64), 0, st, partial, nb64, cost, kb);
+  else if (blk_hi > blk_lo)
+    hipLaunchKernelGGL(kmeans_partial_export_kernel, dim3((blk_hi - blk_lo + 255) / 256, L), dim3(256), 0, st, partial,
+                       nb64, blk_lo, blk_hi, partial_out, kb);
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 
@@ -1619,6 +1663,40 @@ extern "C" int nif_kmeans_repair_kf_batch(int32_t* assign, double* nearest, cons
   nif::Range nif_range_("nif_kmeans_repair_kf_batch");
   if (!tries_idx) return NIF_ERR_INVALID_ARG;
   return nif::km_repair_kf(assign, nearest, s, prev, N, k, tries_idx, n_tries, changed, ws, ws_bytes, stream);
+}
+
+extern "C" int nif_kmeans_lloyd_step_range(const double* G, int64_t ldg, const double* nn, const float* s,
+                                           const int32_t* assign, int N, int k, const int32_t* tries_idx, int n_tries,
+                                           int blk_lo, int blk_hi, int32_t* assign_out, double* nearest,
+                                           double* partial, int32_t* kprime, void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_kmeans_lloyd_step_range");
+  if (!partial) return NIF_ERR_INVALID_ARG;
+  return nif::km_lloyd_step<double>(G, ldg, nullptr, nn, s, assign, N, k, tries_idx, tries_idx ? n_tries : 1, assign_out,
+                                    nearest, nullptr, kprime, ws, ws_bytes, stream, blk_lo, blk_hi, partial);
+}
+extern "C" int nif_kmeans_lloyd_step_range_gf32(const float* G, int64_t ldg, const double* gdiag, const double* nn,
+                                                const float* s, const int32_t* assign, int N, int k,
+                                                const int32_t* tries_idx, int n_tries, int blk_lo, int blk_hi,
+                                                int32_t* assign_out, double* nearest, double* partial, int32_t* kprime,
+                                                void* ws, size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_kmeans_lloyd_step_range_gf32");
+  if (!partial) return NIF_ERR_INVALID_ARG;
+  return nif::km_lloyd_step<float>(G, ldg, gdiag, nn, s, assign, N, k, tries_idx, tries_idx ? n_tries : 1, assign_out,
+                                   nearest, nullptr, kprime, ws, ws_bytes, stream, blk_lo, blk_hi, partial);
+}
+extern "C" int nif_kmeans_cost_from_partials(const double* partial, int nblocks, const int32_t* tries_idx, int n_tries,
+                                             double* cost, void* stream) {
+  nif::Range nif_range_("nif_kmeans_cost_from_partials");
+  using namespace nif;
+  if (!partial || !cost || nblocks <= 0) return NIF_ERR_INVALID_ARG;
+  const int L = tries_idx ? n_tries : 1;
+  KmBatch kb;
+  const int brc = km_batch(tries_idx, L, 0, 0, &kb);
+  if (brc != NIF_OK) return brc;
+  clear_err();
+  hipLaunchKernelGGL(kmeans_cost_rows_kernel, dim3(1, L), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), partial,
+                     nblocks, cost, kb);
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 
 extern "C" int nif_kmeans_centroid_weights(const double* W, int64_t ldw, const float* s, const int32_t* assign, int N,

@@ -726,8 +726,38 @@ class KMeans:
                      _stream()), 'nif_kmeans_assign_to_neurons' + self._sfx)
         return assign
 
+    def _lloyd_step_sharded(self, assign, arr, L, share):
+        """The step with its pass over G split by neuron over the ranks of a parallel.SampleSharding(shard_lloyd=True)
+        context (every rank holds the same G, assign, s): this rank's 64-neuron blocks, then one all-reduce each for
+        the labels and for distances + cost shares (every entry has one writer: exact), then the cost in the
+        unsharded step's order.  Rows of tries outside `arr` stay zero."""
+        from . import parallel
+        lo, hi, group = share
+        T = self.tries if arr is not None else 1
+        nb = (self.N + 63) // 64
+        with torch.cuda.device(self.dev):
+            out = torch.zeros((T, self.N), dtype=torch.int32, device=self.dev)
+            f = torch.zeros(T * (self.N + nb), dtype=torch.float64, device=self.dev)  # distances | cost shares
+            nearest, partial = f[:T * self.N].view(T, self.N), f[T * self.N:].view(T, nb)
+            cost = torch.zeros(T, dtype=torch.float64, device=self.dev)
+            kprime = torch.zeros(T, dtype=torch.int32, device=self.dev)
+            fn = getattr(lib, 'nif_kmeans_lloyd_step_range' + self._sfx)
+            check(fn(_ptr(self.G), self.G.stride(0), *self._g, _ptr(self.nn), _ptr(self.s), _ptr(assign), self.N, self.k,
+                     arr, L, lo, hi, _ptr(out), _ptr(nearest), _ptr(partial), _ptr(kprime), _ptr(self.ws),
+                     self.nbytes * T, _stream()), 'nif_kmeans_lloyd_step_range' + self._sfx)
+            parallel.all_reduce_sum(out, group)
+            parallel.all_reduce_sum(f, group)
+            check(lib.nif_kmeans_cost_from_partials(_ptr(partial), nb, arr, L, _ptr(cost), _stream()),
+                  'nif_kmeans_cost_from_partials')
+        return out, nearest, cost, kprime
+
     def lloyd_step(self, assign):
         """(assign_out, nearest, cost, kprime): cost / kprime are 0-d device tensors."""
+        from .parallel import SampleSharding
+        share = SampleSharding.lloyd_blocks((self.N + 63) // 64)
+        if share is not None:
+            out, nearest, cost, kprime = self._lloyd_step_sharded(assign.contiguous(), None, 1, share)
+            return out[0], nearest[0], cost[0], kprime[0]
         with torch.cuda.device(self.dev):
             out = self._i32(self.N)
             nearest = torch.empty(self.N, dtype=torch.float64, device=self.dev)
@@ -751,6 +781,10 @@ class KMeans:
         left unwritten."""
         arr, L = self._live(live)
         assign = assign.contiguous()
+        from .parallel import SampleSharding
+        share = SampleSharding.lloyd_blocks((self.N + 63) // 64)
+        if share is not None:
+            return self._lloyd_step_sharded(assign, arr, L, share)
         with torch.cuda.device(self.dev):
             out = torch.empty((self.tries, self.N), dtype=torch.int32, device=self.dev)
             nearest = torch.empty((self.tries, self.N), dtype=torch.float64, device=self.dev)

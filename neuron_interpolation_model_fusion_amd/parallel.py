@@ -198,8 +198,11 @@ class SampleSharding:
     """
     _active = None
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, shard_lloyd=None):
         self.group = group
+        # opt-in: the k-means Lloyd steps of HF / KF / ALF split their pass over the (reduced, replicated) Gram by
+        # neuron as well, one small all-reduce per step (ops.KMeans.lloyd_step); same bits as the replicated step
+        self.shard_lloyd = os.environ.get('NIF_SHARD_LLOYD') == '1' if shard_lloyd is None else bool(shard_lloyd)
 
     def __enter__(self):
         self._prev = SampleSharding._active
@@ -209,6 +212,20 @@ class SampleSharding:
     def __exit__(self, *exc):
         SampleSharding._active = self._prev
         return False
+
+    @classmethod
+    def lloyd_blocks(cls, nblocks):
+        """(lo, hi, group): this rank's contiguous share of `nblocks` 64-neuron blocks in a neuron-sharded Lloyd step,
+        or None when the step is to run whole (no context, not opted in, one rank)."""
+        act = cls._active
+        if act is None or not act.shard_lloyd or not dist.is_initialized():
+            return None
+        world = dist.get_world_size(act.group)
+        if world <= 1:
+            return None
+        per = -(-nblocks // world)
+        r = dist.get_rank(act.group)
+        return min(nblocks, r * per), min(nblocks, (r + 1) * per), act.group
 
     @classmethod
     def wants_packed(cls, n):

@@ -657,6 +657,45 @@ def test_kmeans_lloyd_step_matches_f64_reference(ops, N, k, m, empty):
     np.testing.assert_allclose(float(cost), c, rtol=1e-9)
 
 
+@pytest.mark.parametrize('N,k,cuts', [(1000, 64, (0, 5, 16)), (6000, 40, (0, 1, 50, 50, 94)), (130, 9, (0, 3)), (40, 5, (0, 0, 1))])
+def test_kmeans_lloyd_step_in_block_ranges_equals_the_whole_step(ops, N, k, cuts):
+    """nif_kmeans_lloyd_step_range over consecutive 64-neuron block ranges (what the ranks of a neuron-sharded step
+    each do) + nif_kmeans_cost_from_partials = nif_kmeans_lloyd_step, bit for bit; N = 6000 carries a big cluster."""
+    import ctypes
+    from neuron_interpolation_model_fusion_amd._lib import lib, check
+    A, s, assign = _kmeans_problem(N, k, 24, 3 * N + k)
+    if N == 6000:
+        assign[torch.randperm(N, generator=torch.Generator().manual_seed(1))[:2500]] = 2
+    G, _, _ = ops.xty(A.double().cuda(), None, acc='f64', norms=False)
+    gd = torch.diagonal(G).contiguous()
+    nb = (N + 63) // 64
+    assert cuts[-1] == nb
+    for Gs, sfx in ((G, ''), (G.float(), '_gf32')):
+        km = ops.KMeans(Gs, gd, s.cuda(), k, gdiag=gd)
+        out, nearest, cost, kp = km.lloyd_step(assign.cuda())
+        a = assign.cuda()
+        out_r = torch.zeros(N, dtype=torch.int32, device='cuda')
+        near_r = torch.zeros(N, dtype=torch.float64, device='cuda')
+        part = torch.zeros(nb, dtype=torch.float64, device='cuda')
+        cost_r = torch.zeros((), dtype=torch.float64, device='cuda')
+        kp_r = torch.zeros((), dtype=torch.int32, device='cuda')
+        g = (gd.data_ptr(),) if sfx else ()
+        fn = getattr(lib, 'nif_kmeans_lloyd_step_range' + sfx)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            check(fn(Gs.data_ptr(), Gs.stride(0), *g, km.nn.data_ptr(), km.s.data_ptr(), a.data_ptr(), N, k, None, 1, lo, hi,
+                     out_r.data_ptr(), near_r.data_ptr(), part.data_ptr(), kp_r.data_ptr(), km.ws.data_ptr(), km.nbytes,
+                     torch.cuda.current_stream().cuda_stream), 'range')
+        check(lib.nif_kmeans_cost_from_partials(part.data_ptr(), nb, None, 1, cost_r.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), 'cost')
+        assert torch.equal(out_r, out) and torch.equal(near_r, nearest) and int(kp_r) == int(kp)
+        assert float(cost_r) == float(cost)
+        # a range outside the layer is refused
+        rc = fn(Gs.data_ptr(), Gs.stride(0), *g, km.nn.data_ptr(), km.s.data_ptr(), a.data_ptr(), N, k, None, 1, 0, nb + 1,
+                out_r.data_ptr(), near_r.data_ptr(), part.data_ptr(), kp_r.data_ptr(), km.ws.data_ptr(), km.nbytes,
+                torch.cuda.current_stream().cuda_stream)
+        assert rc != 0
+
+
 @pytest.mark.parametrize('N,k,m,sizes', [(6000, 40, 48, (3000,)), (9000, 64, 32, (1025, 4100, 1024)), (5000, 3, 24, (2500, 2400)),
                                           (3000, 8, 16, (2993,))])
 def test_kmeans_lloyd_step_clusters_above_the_chunking_threshold(ops, N, k, m, sizes):
