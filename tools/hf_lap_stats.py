@@ -33,3 +33,6 @@ for rep in range(2):
         LSFusion(models).fuse(X, None, 'hungarian')
 for n, path, ms, st in log:
     print(f'n={n} path={path} {ms:.2f} ms (steps, passes, free) = {st}')
+print(f'total {sum(ms for _, _, ms, _ in log):.2f} ms over {len(log)} assignments '
+      f'(NIF_LAP_ARR_PASSES={os.environ.get("NIF_LAP_ARR_PASSES", "-")}, MIN_CHAINS={os.environ.get("NIF_LAP_ARR_MIN_CHAINS", "-")}, '
+      f'MAX_WAIT={os.environ.get("NIF_LAP_ARR_MAX_WAIT", "-")})')
