@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .base_model import BaseModel, WeightRepresentation, LevelRepresentation
+from .conv import GemmConv2d
 
 
 class VGG(BaseModel):
@@ -42,7 +43,7 @@ class VGG(BaseModel):
             if item == 'M':
                 pending.append(nn.MaxPool2d(kernel_size=2, stride=2))
                 continue
-            pending.append(nn.Conv2d(channels, item, kernel_size=3, padding=1, bias=use_bias))
+            pending.append(GemmConv2d(channels, item, kernel_size=3, padding=1, bias=use_bias))
             if batch_norm:
                 pending.append(nn.BatchNorm2d(item))
             if use_activations:

@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from ..models.mlp import MLPNet
 from ..models.vgg import VGG
+from ..models.conv import GemmConv2d
 from ..models.vit import MultiHeadSelfAttention, InputEmbedder, TransformerEncoder, ViT
 
 # reference module path -> classes it pickles under that path (run_utils.py:9-14)
@@ -27,7 +28,7 @@ _TORCH_CLASSES = [
     nn.Linear, nn.Dropout, nn.Conv2d, nn.MaxPool2d, nn.AvgPool2d, nn.Dropout2d, nn.BatchNorm2d, nn.Parameter,
     nn.TransformerEncoderLayer, nn.MultiheadAttention, nn.modules.linear.NonDynamicallyQuantizableLinear,
     nn.LayerNorm, nn.Sequential, nn.ModuleList, nn.ReLU, nn.GELU, nn.Flatten, nn.AdaptiveAvgPool2d,
-    nn.AdaptiveMaxPool2d, set,
+    nn.AdaptiveMaxPool2d, set, GemmConv2d,
 ]
 
 

@@ -104,7 +104,16 @@ def test_hf_matches_reference_golden(dev, name):
             wref = np.concatenate([z[f'hf.w0_{l}'], z[f'hf.w1_{l}']], axis=1)
             w = info['W'].cpu().numpy()
             assert np.abs(w - wref).max() <= 2e-3 * np.abs(wref).max(), f'LS solution, layer {l}'
-        assert (info['col'].cpu().numpy() == z[f'hf.col{l}']).all(), f'layer {l}'
+        col, col_ref = info['col'].cpu().numpy(), z[f'hf.col{l}']
+        if l == n_layers - 1 and not (col == col_ref).all():
+            # The output layer's assignment is computed and discarded (identity is used, hf_kf.py:254-255).  On vgg_tiny
+            # its golden optimum leads the runner-up by 2.6e-8 of the total -- below the f32 spacing of the costs, so
+            # the last bit of a captured activation (conv summation order) decides it: same total, to f32, required.
+            rows = np.arange(len(col_ref))
+            tot, tot_ref = ref[rows, col].astype(np.float64).sum(), ref[rows, col_ref].astype(np.float64).sum()
+            assert sorted(col) == list(rows) and abs(tot - tot_ref) <= 1e-6 * abs(tot_ref), f'layer {l}'
+        else:
+            assert (col == col_ref).all(), f'layer {l}'
     assert_state_close(fused, fused_state(z, 'hf'), rtol=1e-3)
 
 
