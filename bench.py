@@ -387,6 +387,38 @@ def main():
             hard['pipelined_levels_per_s'] = args.hard_steps / tp
             hard['pipelined_ms_per_step'] = tp / args.hard_steps * 1e3
             hard['pipelined_lap_kernel_ms'] = lap_ms / max(lap_n, 1)
+        # The way the product runs independent levels (OTFusion's activation mode and Git Re-Basin pre-solve the plans of
+        # ALL layers side by side, ops.lap_solve_many: their ground metrics come from activations captured once): the
+        # Grams of a batch of levels back to back with the whole chip each, then their single-workgroup assignments
+        # together on their own streams -- each on a CU of its own, with no Gram traffic beside them -- then the refits.
+        batch = int(os.environ.get('NIF_BENCH_HARD_BATCH', '8'))
+        if batch > 1:
+            def hard_batch():
+                fronts = [level_front(ops, lvh) for _ in range(batch)]
+                costs = [ops.cost_dist(f[0], f[1], f[2]) for f in fronts]
+                cols, rows4col = ops.lap_solve_many(costs, scipy_order=False, rows=True)
+                for row in rows4col:
+                    w = ops.refit_gather(lvh['w_f'], lvh['w_k'], rowsrc=row, colsrc=lvh['prev'], alpha=0.5, beta=0.5)
+                    b = ops.refit_gather(lvh['b_f'], lvh['b_k'], rowsrc=row, alpha=0.5, beta=0.5)
+                return cols, w, b
+            serial_col = level_step(ops, lvh)[0]
+            cols, _, _ = hard_batch()
+            torch.cuda.synchronize()
+            same = all(bool(torch.equal(c, serial_col)) for c in cols)
+            nb = max(1, (args.hard_steps + batch - 1) // batch)
+            tb = time.perf_counter()
+            for _ in range(nb):
+                hard_batch()
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            hard['batched_levels_per_s'] = nb * batch / tb
+            hard['batched_ms_per_step'] = tb / (nb * batch) * 1e3
+            hard['batch'] = batch
+            hard['batched_steps'] = nb * batch
+            hard['batched_assignment_equals_serial'] = same
+            hard['batched_note'] = ('levels in batches: Grams back to back, then the batch\'s assignments side by side on their '
+                                    'own streams (ops.lap_solve_many, what OTFusion / Git Re-Basin do for the layers of a fusion), '
+                                    'then the refits')
         del lvh
 
     # Third figure (N = 1): the same level with the ADDITIONAL Sinkhorn solver in place of the exact assignment
