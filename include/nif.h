@@ -182,6 +182,20 @@ size_t nif_lap_workspace_bytes(int n);
 int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
                       double* u, double* v, void* ws, size_t ws_bytes, void* stream);
 
+/* `batch` independent problems of ONE size in one call: the layers of Git Re-Basin / OTFusion in activation mode
+ * (git_rebasin.py:112 and otfusion.py:309 run once per layer, on costs that come from activations captured once, so
+ * nothing orders them), or the same layer of several models against one target (otfusion.py:300-343 loops over the
+ * models).  Problem p reads C + p * stride_c (stride_c >= (n - 1) * ldc + n) and writes entries [p * n, (p + 1) * n)
+ * of col4row / row4col / u / v (all required here).  Every kernel of nif_lap_solve_f32 is launched once with the
+ * problems along gridDim.z, so the single-workgroup phases of the problems run on `batch` compute units side by
+ * side instead of one after the other; each problem's results are bit-identical to its own nif_lap_solve_f32 call.
+ * `flags` as for nif_lap_solve_f32, the same for every problem.  Workspace: nif_lap_batch_workspace_bytes(n, batch)
+ * (= batch * nif_lap_workspace_bytes(n)); batch <= 65535. */
+size_t nif_lap_batch_workspace_bytes(int n, int batch);
+int nif_lap_solve_batch_f32(const float* C, int64_t ldc, int64_t stride_c, int n, int batch, int flags,
+                            int32_t* col4row, int32_t* row4col, double* u, double* v, void* ws, size_t ws_bytes,
+                            void* stream);
+
 /* The same solve for callers that cannot allocate device memory or hand over a workspace (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference.  The
  * scratch the kernels need (column-minimum partials, claim words, stand-ins for optional outputs) lives in a

@@ -55,6 +55,8 @@ SIGNATURES = {
     'nif_lap_workspace_bytes': (_sz, [_i32]),
     'nif_lap_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nif_lap_solve_f32_static': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'nif_lap_batch_workspace_bytes': (_sz, [_i32, _i32]),
+    'nif_lap_solve_batch_f32': (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nif_kmeans_workspace_bytes': (_sz, [_i32, _i32]),
     'nif_kmeans_farthest_init': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'nif_kmeans_assign_to_neurons': (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp]),

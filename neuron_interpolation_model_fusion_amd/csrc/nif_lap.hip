@@ -25,8 +25,19 @@ namespace nif {
 
 constexpr int LAP_CHUNKS_MAX = 64;
 
+// Strided batch of independent problems of one size (nif_lap_solve_batch_f32): problem blockIdx.z of a launch reads /
+// writes its own slice of every array.  Strides in elements of the array's type; all zero (and gridDim.z = 1) for a
+// single problem.  The per-problem workspace arrays (partials, best columns, claims) are `ws` elements of 4 bytes apart.
+struct LapBatch {
+  int64_t c = 0;    // cost matrices
+  int64_t vec = 0;  // u, v, col4row, row4col (n entries per problem)
+  int64_t ws = 0;   // partials / jbest / claim inside the workspace
+};
+
 __global__ void lap_colmin_partial_kernel(const float* __restrict__ C, int64_t ldc, int n, int rows_per_chunk,
-                                          float* __restrict__ part) {
+                                          float* __restrict__ part, LapBatch bt) {
+  C += blockIdx.z * bt.c;
+  part += blockIdx.z * bt.ws;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int r0 = blockIdx.y * rows_per_chunk;
@@ -46,7 +57,10 @@ __global__ void lap_colmin_partial_kernel(const float* __restrict__ C, int64_t l
 }
 
 __global__ void lap_colmin_final_kernel(const float* __restrict__ part, int chunks, int n, double* __restrict__ v,
-                                        int* __restrict__ claim) {
+                                        int* __restrict__ claim, LapBatch bt) {
+  part += blockIdx.z * bt.ws;
+  v += blockIdx.z * bt.vec;
+  claim += blockIdx.z * bt.ws;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   float mn = INFINITY;
@@ -57,7 +71,12 @@ __global__ void lap_colmin_final_kernel(const float* __restrict__ part, int chun
 
 // one wavefront per row
 __global__ void lap_rowmin_kernel(const float* __restrict__ C, int64_t ldc, int n, const double* __restrict__ v,
-                                  double* __restrict__ u, int* __restrict__ jbest, int* __restrict__ claim) {
+                                  double* __restrict__ u, int* __restrict__ jbest, int* __restrict__ claim, LapBatch bt) {
+  C += blockIdx.z * bt.c;
+  v += blockIdx.z * bt.vec;
+  u += blockIdx.z * bt.vec;
+  jbest += blockIdx.z * bt.ws;
+  claim += blockIdx.z * bt.ws;
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -90,7 +109,11 @@ __global__ void lap_rowmin_kernel(const float* __restrict__ C, int64_t ldc, int 
 }
 
 __global__ void lap_greedy_finish_kernel(int n, const int* __restrict__ jbest, const int* __restrict__ claim,
-                                         int* __restrict__ col4row, int* __restrict__ row4col) {
+                                         int* __restrict__ col4row, int* __restrict__ row4col, LapBatch bt) {
+  jbest += blockIdx.z * bt.ws;
+  claim += blockIdx.z * bt.ws;
+  col4row += blockIdx.z * bt.vec;
+  row4col += blockIdx.z * bt.vec;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int jb = jbest[t];
@@ -106,7 +129,11 @@ __global__ void lap_greedy_finish_kernel(int n, const int* __restrict__ jbest, c
 // highest position if any is free, else the column of lowest position.
 
 __global__ void lap_zero_init_kernel(int n, double* __restrict__ u, double* __restrict__ v, int* __restrict__ col4row,
-                                     int* __restrict__ row4col) {
+                                     int* __restrict__ row4col, LapBatch bt) {
+  u += blockIdx.z * bt.vec;
+  v += blockIdx.z * bt.vec;
+  col4row += blockIdx.z * bt.vec;
+  row4col += blockIdx.z * bt.vec;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   u[t] = 0.0;
@@ -127,7 +154,13 @@ template <int CPT, bool SCIPY, bool ONE = false>
 __global__ __launch_bounds__(1024) void lap_augment_kernel(const float* __restrict__ C, int64_t ldc, int n,
                                                            double* __restrict__ u, double* __restrict__ vg,
                                                            int* __restrict__ col4row_g, int* __restrict__ row4col_g,
-                                                           int* __restrict__ stats, int max_steps) {
+                                                           int* __restrict__ stats, int max_steps, LapBatch bt) {
+  C += blockIdx.z * bt.c;
+  u += blockIdx.z * bt.vec;
+  vg += blockIdx.z * bt.vec;
+  col4row_g += blockIdx.z * bt.vec;
+  row4col_g += blockIdx.z * bt.vec;
+  stats += blockIdx.z * bt.ws;
   extern __shared__ __attribute__((aligned(16))) int lap_sm[];
   int* path = lap_sm;
   int* row4col = lap_sm + n;
@@ -384,7 +417,13 @@ __global__ __launch_bounds__(1024) void lap_arr_kernel(const float* __restrict__
                                                        double* __restrict__ u, double* __restrict__ vg,
                                                        int* __restrict__ col4row_g, int* __restrict__ row4col_g,
                                                        int* __restrict__ stats, int max_passes, int min_chains,
-                                                       int max_wait) {
+                                                       int max_wait, LapBatch bt) {
+  C += blockIdx.z * bt.c;
+  u += blockIdx.z * bt.vec;
+  vg += blockIdx.z * bt.vec;
+  col4row_g += blockIdx.z * bt.vec;
+  row4col_g += blockIdx.z * bt.vec;
+  stats += blockIdx.z * bt.ws;
   extern __shared__ __attribute__((aligned(16))) int lap_sm[];
   double* v = reinterpret_cast<double*>(lap_sm);
   int* row4col = reinterpret_cast<int*>(v + n);
@@ -798,10 +837,10 @@ static LapWs lap_ws(int n) {
 
 template <int CPT, bool SCIPY, bool ONE = false>
 static void launch_augment(int threads, size_t lds, hipStream_t st, const float* C, int64_t ldc, int n, double* u,
-                           double* v, int* c4r, int* r4c, int* stats, int max_steps) {
+                           double* v, int* c4r, int* r4c, int* stats, int max_steps, int batch, LapBatch bt) {
   auto kfn = lap_augment_kernel<CPT, SCIPY, ONE>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(1), dim3(threads), lds, st, C, ldc, n, u, v, c4r, r4c, stats, max_steps);
+  hipLaunchKernelGGL(kfn, dim3(1, 1, batch), dim3(threads), lds, st, C, ldc, n, u, v, c4r, r4c, stats, max_steps, bt);
 }
 
 }  // namespace nif
@@ -815,8 +854,10 @@ namespace nif {
 // Both entry points below run this: `ws` is the caller's workspace (nif_lap_solve_f32) or the per-device address of
 // the library's static scratch array (nif_lap_solve_f32_static).  `timed` = record the NIF_PROF_LAP span (creates
 // HIP events, which allocates: the static entry point never asks for it).
+// batch > 1: `batch` problems of size n, cost matrices stride_c floats apart, outputs n entries apart, workspaces
+// lap_ws(n).total bytes apart; every kernel runs once with the problems along gridDim.z (u, v, row4col required).
 static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col, double* u,
-                        double* v, void* ws, hipStream_t st, bool timed);
+                        double* v, void* ws, hipStream_t st, bool timed, int batch = 1, int64_t stride_c = 0);
 }  // namespace nif
 
 extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col,
@@ -827,6 +868,24 @@ extern "C" int nif_lap_solve_f32(const float* C, int64_t ldc, int n, int flags, 
   if (n > NIF_LAP_MAX_N) return NIF_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < lap_ws(n).total) return NIF_ERR_WORKSPACE;
   return lap_solve_on(C, ldc, n, flags, col4row, row4col, u, v, ws, reinterpret_cast<hipStream_t>(stream), true);
+}
+
+extern "C" size_t nif_lap_batch_workspace_bytes(int n, int batch) {
+  if (n <= 0 || n > NIF_LAP_MAX_N || batch <= 0) return 0;
+  return nif::lap_ws(n).total * (size_t)batch;
+}
+
+extern "C" int nif_lap_solve_batch_f32(const float* C, int64_t ldc, int64_t stride_c, int n, int batch, int flags,
+                                       int32_t* col4row, int32_t* row4col, double* u, double* v, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_lap_solve_batch_f32");
+  using namespace nif;
+  if (!C || !col4row || !row4col || !u || !v || n <= 0 || ldc < n || batch <= 0 || batch > 65535) return NIF_ERR_INVALID_ARG;
+  if (batch > 1 && stride_c < (int64_t)(n - 1) * ldc + n) return NIF_ERR_INVALID_ARG;  // problems must not overlap
+  if (n > NIF_LAP_MAX_N) return NIF_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < lap_ws(n).total * (size_t)batch) return NIF_ERR_WORKSPACE;
+  return lap_solve_on(C, ldc, n, flags, col4row, row4col, u, v, ws, reinterpret_cast<hipStream_t>(stream), true, batch,
+                      stride_c);
 }
 
 // ---- the entry point that allocates nothing -------------------------------------------------------------------
@@ -881,8 +940,16 @@ extern "C" int nif_lap_solve_f32_static(const float* C, int64_t ldc, int n, int 
 
 namespace nif {
 static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* col4row, int32_t* row4col, double* u,
-                        double* v, void* ws, hipStream_t st, bool timed) {
+                        double* v, void* ws, hipStream_t st, bool timed, int batch, int64_t stride_c) {
   const LapWs w = lap_ws(n);
+  LapBatch bt;
+  if (batch > 1) {
+    if (!u || !v || !row4col) return NIF_ERR_INVALID_ARG;
+    bt.c = stride_c;
+    bt.vec = n;
+    bt.ws = (int64_t)(w.total / 4);
+  }
+  const unsigned bz = (unsigned)batch;
   clear_err();
   unsigned char* b = reinterpret_cast<unsigned char*>(ws);
   float* part = reinterpret_cast<float*>(b + w.off_part);
@@ -900,13 +967,13 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
   if (resume) {
     // u, v, col4row, row4col hold the state an INIT_ONLY call left: go straight to the augmenting paths
   } else if (scipy_order) {
-    hipLaunchKernelGGL(lap_zero_init_kernel, dim3(nb), dim3(256), 0, st, n, uu, vv, col4row, r4c);
+    hipLaunchKernelGGL(lap_zero_init_kernel, dim3(nb, 1, bz), dim3(256), 0, st, n, uu, vv, col4row, r4c, bt);
   } else {
-  hipLaunchKernelGGL(lap_colmin_partial_kernel, dim3(nb, w.chunks), dim3(256), 0, st, C, ldc, n, w.rows_per_chunk,
-                     part);
-  hipLaunchKernelGGL(lap_colmin_final_kernel, dim3(nb), dim3(256), 0, st, part, w.chunks, n, vv, claim);
-  hipLaunchKernelGGL(lap_rowmin_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, ldc, n, vv, uu, jbest, claim);
-  hipLaunchKernelGGL(lap_greedy_finish_kernel, dim3(nb), dim3(256), 0, st, n, jbest, claim, col4row, r4c);
+  hipLaunchKernelGGL(lap_colmin_partial_kernel, dim3(nb, w.chunks, bz), dim3(256), 0, st, C, ldc, n, w.rows_per_chunk,
+                     part, bt);
+  hipLaunchKernelGGL(lap_colmin_final_kernel, dim3(nb, 1, bz), dim3(256), 0, st, part, w.chunks, n, vv, claim, bt);
+  hipLaunchKernelGGL(lap_rowmin_kernel, dim3((n + 3) / 4, 1, bz), dim3(256), 0, st, C, ldc, n, vv, uu, jbest, claim, bt);
+  hipLaunchKernelGGL(lap_greedy_finish_kernel, dim3(nb, 1, bz), dim3(256), 0, st, n, jbest, claim, col4row, r4c, bt);
   }
   if (!launch_ok()) return NIF_ERR_LAUNCH;
   if (init_only) return NIF_OK;
@@ -927,8 +994,8 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
     auto kfn = lap_arr_kernel<CPT>;                                                                                   \
     if (arr_lds > 48 * 1024)                                                                                          \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)arr_lds);          \
-    hipLaunchKernelGGL(kfn, dim3(1), dim3(1024), arr_lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, arr_passes,    \
-                       arr_min_chains, arr_max_wait);                                                               \
+    hipLaunchKernelGGL(kfn, dim3(1, 1, bz), dim3(1024), arr_lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, arr_passes, \
+                       arr_min_chains, arr_max_wait, bt);                                                           \
   } while (0)
       const int cols = (n + 63) / 64;  // columns a lane holds of its bidder's row
       if (cols <= 2) NIF_ARR_GO(2);
@@ -963,8 +1030,8 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
   const size_t lds = (size_t)((3 * n + 3) & ~3) * sizeof(int) + LAP_MBOX_TOTAL * sizeof(int);
 #define NIF_LAP_GO(CPT, ONE)                                                                       \
   do {                                                                                        \
-    if (scipy_order) launch_augment<CPT, true, ONE>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, 0); \
-    else launch_augment<CPT, false, ONE>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, max_steps);       \
+    if (scipy_order) launch_augment<CPT, true, ONE>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, 0, batch, bt); \
+    else launch_augment<CPT, false, ONE>(threads, lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, max_steps, batch, bt); \
   } while (0)
   if (threads == 64 && cpt == 1) NIF_LAP_GO(1, true);
   else if (threads == 64 && cpt == 2) NIF_LAP_GO(2, true);

@@ -277,6 +277,40 @@ def lap_solve(C, duals=False, scipy_order=False):
     return col
 
 
+LAP_BATCH_STACK_MAX_N = 2048  # lap_solve_many stacks same-size cost matrices (a copy) up to this size
+
+
+def lap_solve_batch(C, duals=False, flags=0):
+    """The fast assignment solver (``lap_solve(C)``) on a stack of independent problems of one size, C [B, n, n] f32
+    (row stride and problem stride taken from the tensor): ONE launch per kernel for the whole stack, the
+    single-workgroup phases of the B problems side by side on B compute units (nif_lap_solve_batch_f32).  Returns
+    col4row [B, n] int32 -- row b is bit-identical to ``lap_solve(C[b])`` -- and with duals=True (col4row, row4col, u, v).
+    ``flags``: NIF_LAP_* of nif_lap_solve_f32, the same for every problem (0 = the fast path)."""
+    _need_gpu(C)
+    if C.dtype != torch.float32 or C.dim() != 3 or C.shape[1] != C.shape[2]:
+        raise TypeError('lap_solve_batch needs a [B, n, n] float32 tensor')
+    B, n = C.shape[0], C.shape[1]
+    if n > _lib.NIF_LAP_MAX_N:
+        raise _lib.NifError(f'lap_solve_batch: n={n} exceeds NIF_LAP_MAX_N={_lib.NIF_LAP_MAX_N}')
+    if B == 0:
+        raise ValueError('lap_solve_batch: empty batch')
+    if C.stride(2) != 1 or C.stride(1) < n or (B > 1 and C.stride(0) < (n - 1) * C.stride(1) + n):
+        C = C.contiguous()
+    with torch.cuda.device(C.device):
+        col = torch.empty((B, n), dtype=torch.int32, device=C.device)
+        row = torch.empty((B, n), dtype=torch.int32, device=C.device)
+        u = torch.empty((B, n), dtype=torch.float64, device=C.device)
+        v = torch.empty((B, n), dtype=torch.float64, device=C.device)
+        nbytes = lib.nif_lap_batch_workspace_bytes(n, B)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=C.device)
+        lap_solve_batch.last_workspace = ws
+        check(lib.nif_lap_solve_batch_f32(_ptr(C), C.stride(1), C.stride(0), n, B, flags, _ptr(col), _ptr(row), _ptr(u),
+                                          _ptr(v), _ptr(ws), nbytes, _stream()), 'nif_lap_solve_batch_f32')
+    if duals:
+        return col, row, u, v
+    return col
+
+
 def lap_solve_many(costs, scipy_order=True, rows=False):
     """``lap_solve(C, scipy_order=scipy_order)`` for several independent square f32 cost matrices at once (the layers of
     Git Re-Basin / OTFusion in activation mode: their costs come from activations captured once, so nothing orders the
@@ -322,8 +356,20 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                 main.wait_stream(p['stream'])
 
         if not scipy_order:
+            # problems of one size go through ONE batched call (their single-workgroup phases side by side on as many
+            # compute units, one launch per kernel); the rest on their own streams (a process has 4 hardware queues, so
+            # streams alone overlap four problems at most)
+            groups = {}
             for p in P:
-                run(p, 0)
+                groups.setdefault(p['n'], []).append(p)
+            for n_, ps in groups.items():
+                if len(ps) >= 2 and n_ <= LAP_BATCH_STACK_MAX_N:
+                    col, row, u, v = lap_solve_batch(torch.stack([p['C'] for p in ps]), duals=True)
+                    for b, p in enumerate(ps):
+                        p['col'], p['row'], p['u'], p['v'] = col[b], row[b], u[b], v[b]
+                else:
+                    for p in ps:
+                        run(p, 0)
         else:
             for p in P:
                 p['staged'] = scipy_order is True and p['n'] >= 32

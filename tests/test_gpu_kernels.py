@@ -1177,3 +1177,71 @@ def test_lap_solve_many_equals_one_by_one(ops):
         many = ops.lap_solve_many(costs, scipy_order=True)
         for C, col in zip(costs, many):
             assert (linear_sum_assignment(C.cpu().numpy())[1] == col.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize('n,B', [(1, 3), (37, 5), (130, 4), (384, 9), (1100, 3), (2100, 2)])
+def test_lap_solve_batch_equals_one_call_per_problem(ops, n, B):
+    """nif_lap_solve_batch_f32 (the problems along gridDim.z of every kernel): matchings AND duals bit-identical to one
+    nif_lap_solve_f32 call per problem -- hard instances (unrelated activations), a planted one, a tie-laden one; row and
+    problem strides wider than the matrices; the staged flags (INIT_ONLY, then RESUME) and the scipy-order kernel too."""
+    g = torch.Generator().manual_seed(1000 + n)
+    m = max(2 * n, 64)
+    probs = []
+    for b in range(B):
+        A0 = torch.randn(m, n, generator=g)
+        A1 = torch.randn(m, n, generator=g) if b != 1 else A0[:, torch.randperm(n, generator=g)] + 0.1 * torch.randn(m, n, generator=g)
+        probs.append(torch.cdist(A0.T.contiguous(), A1.T.contiguous()))
+    if B > 2 and n >= 4:
+        probs[2][:, n // 2:n // 2 * 2] = probs[2][:, :n // 2]      # duplicated columns: exact ties
+    big = torch.zeros(B, n + 3, n + 5)
+    for b in range(B):
+        big[b, :n, :n] = probs[b]
+    big = big.cuda()
+    C = big[:, :n, :n]                                               # strides (n + 3) (n + 5), n + 5, 1
+    assert not C.is_contiguous() or n == 0
+    for flags in (0, ops._lib.NIF_LAP_SCIPY_ORDER):
+        col, row, u, v = ops.lap_solve_batch(C, duals=True, flags=flags)
+        for b in range(B):
+            one = ops.lap_solve(C[b], duals=True, scipy_order='replay' if flags else False)
+            for got, ref in zip((col[b], row[b], u[b], v[b]), one):
+                assert torch.equal(got, ref), (n, b, flags)
+        if flags:
+            from scipy.optimize import linear_sum_assignment
+            for b in range(B):
+                assert (linear_sum_assignment(probs[b].numpy())[1] == col[b].cpu().numpy()).all()
+    # staged: initialisation only, then the searches from that state (what the scipy-order call sites do)
+    cols = torch.empty((B, n), dtype=torch.int32, device='cuda')
+    rows = torch.empty_like(cols)
+    u = torch.empty((B, n), dtype=torch.float64, device='cuda')
+    v = torch.empty_like(u)
+    nbytes = ops.lib.nif_lap_batch_workspace_bytes(n, B)
+    assert nbytes == B * ops.lib.nif_lap_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    Cc = C.contiguous()
+    for flags in (ops._lib.NIF_LAP_INIT_ONLY, ops._lib.NIF_LAP_RESUME):
+        ops.check(ops.lib.nif_lap_solve_batch_f32(Cc.data_ptr(), n, n * n, n, B, flags, cols.data_ptr(), rows.data_ptr(),
+                                                  u.data_ptr(), v.data_ptr(), ws.data_ptr(), nbytes, None), 'batch')
+        if flags == ops._lib.NIF_LAP_INIT_ONLY:
+            free_after_init = int((cols < 0).sum())
+    fast = ops.lap_solve_batch(C)
+    assert torch.equal(cols, fast)
+    assert int((cols < 0).sum()) == 0 and free_after_init >= 0
+    # argument checks: overlapping problems, missing outputs, short workspace
+    lib = ops.lib
+    assert lib.nif_lap_solve_batch_f32(Cc.data_ptr(), n, n * n - 1 if n > 1 else -1, n, max(B, 2), 0, cols.data_ptr(), rows.data_ptr(),
+                                       u.data_ptr(), v.data_ptr(), ws.data_ptr(), nbytes, None) == -1
+    assert lib.nif_lap_solve_batch_f32(Cc.data_ptr(), n, n * n, n, B, 0, cols.data_ptr(), None, u.data_ptr(), v.data_ptr(),
+                                       ws.data_ptr(), nbytes, None) == -1
+    assert lib.nif_lap_solve_batch_f32(Cc.data_ptr(), n, n * n, n, B, 0, cols.data_ptr(), rows.data_ptr(), u.data_ptr(),
+                                       v.data_ptr(), ws.data_ptr(), nbytes - 1, None) != 0
+
+
+def test_lap_solve_many_batches_same_size_problems(ops):
+    """Fast mode: problems of one size take the batched call, odd sizes their own streams; same answers as one by one."""
+    g = torch.Generator().manual_seed(5)
+    costs = [torch.rand(n, n, generator=g).cuda() for n in (200, 64, 200, 200, 33, 64)]
+    one = [ops.lap_solve(C) for C in costs]
+    many, rows = ops.lap_solve_many(costs, scipy_order=False, rows=True)
+    for a, b, r in zip(one, many, rows):
+        assert torch.equal(a, b)
+        assert torch.equal(r[b.long()].long(), torch.arange(b.shape[0], device='cuda'))
