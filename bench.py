@@ -390,8 +390,9 @@ def main():
         # The way the product runs independent levels (OTFusion's activation mode and Git Re-Basin pre-solve the plans of
         # ALL layers side by side, ops.lap_solve_many: their ground metrics come from activations captured once): the
         # Grams of a batch of levels back to back with the whole chip each, then their single-workgroup assignments
-        # together on their own streams -- each on a CU of its own, with no Gram traffic beside them -- then the refits.
-        batch = int(os.environ.get('NIF_BENCH_HARD_BATCH', '8'))
+        # together -- one batched call, the problems along gridDim.z of every kernel, each on a CU of its own, with no Gram
+        # traffic beside them -- then the refits.
+        batch = int(os.environ.get('NIF_BENCH_HARD_BATCH', '16'))
         if batch > 1:
             def hard_batch():
                 fronts = [level_front(ops, lvh) for _ in range(batch)]
@@ -416,9 +417,9 @@ def main():
             hard['batch'] = batch
             hard['batched_steps'] = nb * batch
             hard['batched_assignment_equals_serial'] = same
-            hard['batched_note'] = ('levels in batches: Grams back to back, then the batch\'s assignments side by side on their '
-                                    'own streams (ops.lap_solve_many, what OTFusion / Git Re-Basin do for the layers of a fusion), '
-                                    'then the refits')
+            hard['batched_note'] = ('levels in batches: Grams back to back, then the batch\'s assignments side by side in one '
+                                    'batched call (ops.lap_solve_many -> nif_lap_solve_batch_f32; OTFusion / Git Re-Basin solve the '
+                                    'layers of a fusion together the same way), then the refits')
         del lvh
 
     # Third figure (N = 1): the same level with the ADDITIONAL Sinkhorn solver in place of the exact assignment
