@@ -382,6 +382,22 @@ int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, const double*
                       int flags, int32_t* colptr, int32_t* rowidx, double* val, int32_t out_cap, int32_t* status,
                       double* u, double* v, void* ws, size_t ws_bytes, void* stream);
 
+/* `batch` independent SQUARE problems of one size n in one call: OTFusion solves one plan per model and layer
+ * (otfusion.py:300-343 loops over the models, :261 over the layers) on ground metrics that come from activations
+ * captured once, so nothing orders them.  Problem p reads C + p * stride_c, a + p n, b + p n, tol[p] (DEVICE array: the
+ * tolerance of nif_emd_solve_f32, one per problem) and writes colptr + p (n + 1), rowidx / val + p * out_cap, status +
+ * 16 p, u / v + p n (both required).  The assignment start of every problem is one nif_lap_solve_batch_f32 call and
+ * the forest kernel is launched once with the problems along gridDim.z; every problem's plan, duals and status are
+ * bit-identical to its own nif_emd_solve_f32 call with flags 0.  Only what that call runs by default on such problems:
+ * n <= 2048 within the forest kernel's LDS plan, flags 0 or NIF_EMD_ONE_LANE_PATHS; anything else returns
+ * NIF_ERR_UNSUPPORTED (solve those problem by problem).  A problem whose status[0] comes back NIF_ERR_WORKSPACE is
+ * retried by the caller through nif_emd_solve_f32 with NIF_EMD_EDGES_GLOBAL, as there. */
+size_t nif_emd_batch_workspace_bytes(int n, int batch);
+int nif_emd_solve_batch_f32(const float* C, int64_t ldc, int64_t stride_c, int n, int batch, const double* a,
+                            const double* b, const double* tol, int flags, int32_t* colptr, int32_t* rowidx, double* val,
+                            int32_t out_cap, int32_t* status, double* u, double* v, void* ws, size_t ws_bytes,
+                            void* stream);
+
 /* ---- entropic optimal transport (Sinkhorn-Knopp): an ADDITIONAL, approximate plan solver -------------------
  * No counterpart in the reference, which calls the exact ot.emd (otfusion.py:18-32, :309); north_star (2) / SURVEY D1
  * ask for it as a documented-approximate mode with its own HBM roofline.  Restates POT's `ot.sinkhorn(a, b, M, reg)`

@@ -31,6 +31,7 @@ NIF_EMD_COLD_START = 2
 NIF_EMD_ARC_POOL = 4
 NIF_EMD_ONE_LANE_PATHS = 8
 NIF_ERR_WORKSPACE = -2
+NIF_ERR_UNSUPPORTED = -3
 
 _c = ctypes
 _vp, _i32, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -84,6 +85,9 @@ SIGNATURES = {
     'nif_sinkhorn_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _c.c_double, _i32, _c.c_double, _vp, _i64, _vp, _vp, _vp, _vp,
                                 _vp, _sz, _vp]),
     'nif_emd_workspace_bytes': (_sz, [_i32, _i32]),
+    'nif_emd_batch_workspace_bytes': (_sz, [_i32, _i32]),
+    'nif_emd_solve_batch_f32': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                       _vp, _sz, _vp]),
     'nif_emd_solve_f32': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _c.c_double, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),
     'nif_refit_sparse': (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _c.c_float, _i32, _i32, _i32,

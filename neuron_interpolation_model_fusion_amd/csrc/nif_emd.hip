@@ -648,6 +648,15 @@ static EmdTreeLds emd_tree_lds(int n0, int n1, int cpl, bool big) {
 #define EMD_COUNT(p) do {} while (0)
 #endif
 
+// Strided batch of independent problems of one size (nif_emd_solve_batch_f32): problem blockIdx.z reads / writes its own
+// slice of every array.  All zero (and gridDim.z = 1) for a single problem.
+struct EmdBatch {
+  int64_t c = 0;        // cost matrices (floats)
+  int64_t jbest = 0;    // the starting arcs (ints)
+  int64_t ws = 0;       // per-problem workspace regions (bytes, a multiple of 256)
+  const double* tol = nullptr;  // per-problem tolerance (device); null: the scalar argument
+};
+
 template <int CPL, int NW, bool BIG>
 __global__ __launch_bounds__(NW * 64) void emd_tree_kernel(const float* __restrict__ C, int64_t ldc, int n0, int n1,
                                                            const double* __restrict__ a, const double* __restrict__ b,
@@ -658,7 +667,26 @@ __global__ __launch_bounds__(NW * 64) void emd_tree_kernel(const float* __restri
                                                            EmdTreeLds L, int one_lane,
                                                            int out_cap, int* __restrict__ colptr,
                                                            int* __restrict__ rowidx, double* __restrict__ val,
-                                                           int* __restrict__ status) {
+                                                           int* __restrict__ status, EmdBatch bt) {
+  if (bt.tol) {  // a batched launch (uniform test; scalar address arithmetic only)
+    const int64_t pz = blockIdx.z;
+    C += pz * bt.c;
+    a += pz * n0;
+    b += pz * n1;
+    u += pz * n0;
+    vg += pz * n1;
+    jbest += pz * bt.jbest;
+    dem_g += pz * (bt.ws / 8);
+    sup += pz * (bt.ws / 8);
+    cdist_g += pz * (bt.ws / 8);
+    plist_g += pz * (bt.ws / 4);
+    order_g += pz * (bt.ws / 4);
+    colptr += pz * (n1 + 1);
+    rowidx += pz * out_cap;
+    val += pz * out_cap;
+    status += pz * 16;
+    if (bt.tol) tol = bt.tol[pz];
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char emd_tsm[];
   const int N = n0 + n1;
   EmdNode* nodes = reinterpret_cast<EmdNode*>(emd_tsm + L.off_nodes);  // [N]
@@ -1372,30 +1400,30 @@ template <int CPL, int NW, bool BIG>
 static void launch_emd_tree_v(const EmdTreeLds& L, hipStream_t st, const float* C, int64_t ldc, int n0, int n1,
                               const double* a, const double* b, double tol, double* u, double* v, unsigned char* base,
                               const EmdWs& w, int one_lane, int out_cap, int* colptr, int* rowidx, double* val,
-                              int* status) {
+                              int* status, int batch, const EmdBatch& bt, const int* jbest) {
   auto kfn = emd_tree_kernel<CPL, NW, BIG>;
   static PerDeviceOnce attr_once;
   attr_once.run([&] {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   });
-  hipLaunchKernelGGL(kfn, dim3(1), dim3(NW * 64), L.bytes, st, C, ldc, n0, n1, a, b, tol, u, v,
-                     reinterpret_cast<const int*>(base + w.off_jbest), reinterpret_cast<double*>(base + w.off_dem),
+  hipLaunchKernelGGL(kfn, dim3(1, 1, batch), dim3(NW * 64), L.bytes, st, C, ldc, n0, n1, a, b, tol, u, v,
+                     jbest ? jbest : reinterpret_cast<const int*>(base + w.off_jbest), reinterpret_cast<double*>(base + w.off_dem),
                      reinterpret_cast<double*>(base + w.off_sup), reinterpret_cast<double*>(base + w.off_eflow),
                      reinterpret_cast<int*>(base + w.off_arc), reinterpret_cast<int*>(base + w.off_newrows), L, one_lane,
-                     out_cap, colptr, rowidx, val, status);
+                     out_cap, colptr, rowidx, val, status, bt);
 }
 
 template <int CPL, int NW>
 static void launch_emd_tree(const EmdTreeLds& L, hipStream_t st, const float* C, int64_t ldc, int n0, int n1,
                             const double* a, const double* b, double tol, double* u, double* v, unsigned char* base,
                             const EmdWs& w, int one_lane, int out_cap, int* colptr, int* rowidx, double* val,
-                            int* status) {
+                            int* status, int batch = 1, const EmdBatch& bt = EmdBatch(), const int* jbest = nullptr) {
   if (L.big)
     launch_emd_tree_v<CPL, NW, true>(L, st, C, ldc, n0, n1, a, b, tol, u, v, base, w, one_lane, out_cap, colptr, rowidx,
-                                     val, status);
+                                     val, status, batch, bt, jbest);
   else
     launch_emd_tree_v<CPL, NW, false>(L, st, C, ldc, n0, n1, a, b, tol, u, v, base, w, one_lane, out_cap, colptr,
-                                      rowidx, val, status);
+                                      rowidx, val, status, batch, bt, jbest);
 }
 
 // out[j][q*sp + s] = beta * W0[j][q*sp + s]
@@ -1517,6 +1545,80 @@ extern "C" int nif_emd_solve_f32(const float* C, int64_t ldc, int n0, int n1, co
     default: NIF_EMD_GO(8); break;
   }
 #undef NIF_EMD_GO
+  return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
+}
+
+namespace nif {
+struct EmdBatchWs {
+  size_t off_jbest, off_r4c, off_lap, total;
+};
+static EmdBatchWs emd_batch_ws(int n, int batch) {
+  const EmdWs w = emd_ws(n, n);
+  EmdBatchWs bw;
+  size_t o = w.total * (size_t)batch;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += (bytes + 255) & ~(size_t)255;
+    return at;
+  };
+  bw.off_jbest = take((size_t)batch * n * sizeof(int));
+  bw.off_r4c = take((size_t)batch * n * sizeof(int));
+  bw.off_lap = take(nif_lap_batch_workspace_bytes(n, batch));
+  bw.total = o;
+  return bw;
+}
+}  // namespace nif
+
+extern "C" size_t nif_emd_batch_workspace_bytes(int n, int batch) {
+  if (n <= 0 || n > NIF_EMD_MAX_N || batch <= 0 || batch > 65535) return 0;
+  return nif::emd_batch_ws(n, batch).total;
+}
+
+extern "C" int nif_emd_solve_batch_f32(const float* C, int64_t ldc, int64_t stride_c, int n, int batch, const double* a,
+                                       const double* b, const double* tol, int flags, int32_t* colptr, int32_t* rowidx,
+                                       double* val, int32_t out_cap, int32_t* status, double* u, double* v, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  nif::Range nif_range_("nif_emd_solve_batch_f32");
+  using namespace nif;
+  if (!C || !a || !b || !tol || !colptr || !rowidx || !val || !status || !u || !v || n <= 0 || ldc < n || out_cap <= 0 ||
+      batch <= 0 || batch > 65535)
+    return NIF_ERR_INVALID_ARG;
+  if (batch > 1 && stride_c < (int64_t)(n - 1) * ldc + n) return NIF_ERR_INVALID_ARG;
+  if (n > NIF_EMD_MAX_N) return NIF_ERR_UNSUPPORTED;
+  // the forest kernel from the assignment start only (what nif_emd_solve_f32 runs by default on square problems that
+  // fit it); anything else -- wider problems, the tuning flags -- goes through nif_emd_solve_f32 problem by problem
+  if ((flags & ~NIF_EMD_ONE_LANE_PATHS) != 0 || n < 2 || n > 2048 || env_int("NIF_EMD_LEGACY") || env_int("NIF_EMD_COLD_START"))
+    return NIF_ERR_UNSUPPORTED;
+  const EmdWs w = emd_ws(n, n);
+  const EmdBatchWs bw = emd_batch_ws(n, batch);
+  if (!ws || ws_bytes < bw.total) return NIF_ERR_WORKSPACE;
+  const int cpl = (n + 63) / 64;
+  const int cplp = cpl <= 2 ? 2 : cpl <= 4 ? 4 : cpl <= 8 ? 8 : cpl <= 16 ? 16 : 32;
+  EmdTreeLds TL = emd_tree_lds(n, n, cplp, false);
+  if (TL.bytes > 158 * 1024) TL = emd_tree_lds(n, n, cplp, true);
+  if (TL.bytes > 158 * 1024 || ((uint64_t)(n - 1) * (uint64_t)ldc + (uint64_t)n) * 4 >= 0xffffffffull) return NIF_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  unsigned char* base = reinterpret_cast<unsigned char*>(ws);
+  int32_t* jb = reinterpret_cast<int32_t*>(base + bw.off_jbest);
+  clear_err();
+  // the assignment start of every problem in one batched call: col4row = the tight arc each row ships along
+  const int rc = nif_lap_solve_batch_f32(C, ldc, stride_c, n, batch, 0, jb, reinterpret_cast<int32_t*>(base + bw.off_r4c), u, v,
+                                         base + bw.off_lap, nif_lap_batch_workspace_bytes(n, batch), stream);
+  if (rc != NIF_OK) return rc;
+  EmdBatch bt;
+  bt.c = stride_c;
+  bt.jbest = n;
+  bt.ws = (int64_t)w.total;
+  bt.tol = tol;
+#define NIF_EMD_TREE(CPL, NW)                                                                                          \
+  launch_emd_tree<CPL, NW>(TL, st, C, ldc, n, n, a, b, 0.0, u, v, base, w, (flags & NIF_EMD_ONE_LANE_PATHS) ? 1 : 0,     \
+                           out_cap, colptr, rowidx, val, status, batch, bt, jb)
+  if (cpl <= 2) NIF_EMD_TREE(2, 8);
+  else if (cpl <= 4) NIF_EMD_TREE(4, 8);
+  else if (cpl <= 8) NIF_EMD_TREE(8, 8);
+  else if (cpl <= 16) NIF_EMD_TREE(16, 8);
+  else NIF_EMD_TREE(32, 4);
+#undef NIF_EMD_TREE
   return launch_ok() ? NIF_OK : NIF_ERR_LAUNCH;
 }
 

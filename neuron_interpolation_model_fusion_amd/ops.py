@@ -1036,27 +1036,75 @@ def emd_solve(C, a, b, duals=False, flags=0):
     return _emd_result(p, work, duals)
 
 
+EMD_BATCH_MAX_N = 2048  # square problems up to this size can share one batched call (the forest kernel's range)
+
+
+def _emd_launch_batch(group):
+    """One nif_emd_solve_batch_f32 call for square problems of one size: inputs stacked, every problem's output tensors
+    replaced by its rows of the stacked outputs.  False when the library declines (sizes / flags outside the batched
+    path): the caller then solves the group problem by problem."""
+    n, B, dev = group[0]['n0'], len(group), group[0]['dev']
+    cap = group[0]['cap']
+    C = torch.stack([p['C'] for p in group])
+    a = torch.stack([p['a'] for p in group])
+    b = torch.stack([p['b'] for p in group])
+    tol = torch.stack([p['tol'] for p in group]).to(torch.float64).contiguous()
+    colptr = torch.empty((B, n + 1), dtype=torch.int32, device=dev)
+    rowidx = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    val = torch.empty((B, cap), dtype=torch.float64, device=dev)
+    status = torch.zeros((B, 16), dtype=torch.int32, device=dev)
+    u = torch.empty((B, n), dtype=torch.float64, device=dev)
+    v = torch.empty((B, n), dtype=torch.float64, device=dev)
+    wsz = lib.nif_emd_batch_workspace_bytes(n, B)
+    ws = torch.empty(max(wsz, 1), dtype=torch.uint8, device=dev)
+    rc = lib.nif_emd_solve_batch_f32(_ptr(C), n, n * n, n, B, _ptr(a), _ptr(b), _ptr(tol), 0, _ptr(colptr), _ptr(rowidx),
+                                     _ptr(val), cap, _ptr(status), _ptr(u), _ptr(v), _ptr(ws), wsz, _stream())
+    if rc == _lib.NIF_ERR_UNSUPPORTED:
+        return False
+    check(rc, 'nif_emd_solve_batch_f32')
+    for i, p in enumerate(group):
+        p['colptr'], p['rowidx'], p['val'], p['status'], p['u'], p['v'] = colptr[i], rowidx[i], val[i], status[i], u[i], v[i]
+    return True
+
+
 def emd_solve_many(problems, duals=False):
-    """emd_solve for independent problems [(C, a, b), ...], side by side: the solver is one workgroup per problem,
-    so every problem runs on a stream of its own and the statuses are read back once.  Same plans as one by one."""
+    """emd_solve for independent problems [(C, a, b), ...], side by side.  Square problems of one size go through ONE
+    batched call (nif_emd_solve_batch_f32: the assignment start and the forest kernel with the problems along
+    gridDim.z, each on a compute unit of its own); the rest run on a stream each (which overlaps four at a time: a
+    process has four hardware queues).  The statuses are read back once.  Same plans as one by one, bit for bit."""
     if not problems:
         return []
     ps = [_emd_problem(C, a, b) for C, a, b in problems]
     dev = ps[0]['dev']
-    tols = torch.stack([p['tol'] for p in ps]).tolist()  # one read-back for every tolerance
     main = torch.cuda.current_stream(dev)
     with torch.cuda.device(dev):
-        streams = [torch.cuda.Stream(dev) for _ in ps]
-        for p, tol, st in zip(ps, tols, streams):
-            p['tol'] = tol
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                _emd_launch(p, 0, st.cuda_stream)
-        for st in streams:
-            main.wait_stream(st)
+        groups, rest = {}, []
+        for p in ps:
+            if p['n0'] == p['n1'] and 2 <= p['n0'] <= EMD_BATCH_MAX_N:
+                groups.setdefault(p['n0'], []).append(p)
+            else:
+                rest.append(p)
+        for n_, group in groups.items():
+            if len(group) < 2 or not _emd_launch_batch(group):
+                rest.extend(group)
+        if rest:
+            tols = torch.stack([p['tol'] for p in rest]).tolist()  # one read-back for every tolerance
+            streams = [torch.cuda.Stream(dev) for _ in rest]
+            for p, tol, st in zip(rest, tols, streams):
+                p['tol'] = tol
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    _emd_launch(p, 0, st.cuda_stream)
+            for st in streams:
+                main.wait_stream(st)
         works = torch.stack([p['status'] for p in ps]).tolist()
         for i, (p, work) in enumerate(zip(ps, works)):
             if work[0] == _lib.NIF_ERR_WORKSPACE:  # outgrew the LDS arc pool: once more with the pool in global memory
+                if torch.is_tensor(p['tol']):  # a problem of a batched call: its outputs are rows of the stacked tensors
+                    p['tol'] = float(p['tol'])
+                    p['status'] = torch.zeros(16, dtype=torch.int32, device=dev)
+                    for key in ('colptr', 'rowidx', 'val', 'u', 'v'):
+                        p[key] = p[key].clone()
                 _emd_launch(p, _lib.NIF_EMD_EDGES_GLOBAL, _stream())
                 works[i] = p['status'].tolist()
     emd_solve_many.last_work = [dict(augmentations=w[1], steps=w[2], rows_expanded=w[3]) for w in works]

@@ -509,6 +509,46 @@ def test_emd_solve_many_equals_one_by_one(ops):
         assert torch.equal(plan.val, one.val) and torch.equal(u, u1) and torch.equal(v, v1)
 
 
+def test_emd_solve_many_batches_square_problems_of_one_size(ops):
+    """Square problems of one size take nif_emd_solve_batch_f32 (assignment start and forest kernel with the problems
+    along gridDim.z); plans, duals and work counters are those of one nif_emd_solve_f32 call per problem, bit for bit.
+    Mixed in: sizes that occur once and a rectangular problem (their own streams), planted costs, a zero-mass row."""
+    g = torch.Generator().manual_seed(11)
+    probs = []
+    for n0, n1 in [(64, 64), (130, 130), (64, 64), (40, 33), (384, 384), (64, 64), (130, 130), (384, 384), (2, 2), (2, 2),
+                   (17, 17), (600, 600), (600, 600)]:
+        C = torch.rand(n0, n1, generator=g)
+        if len(probs) % 3 == 1 and n0 == n1:   # a planted matching: most of the mass stays on the assignment start
+            C = C + 1.0
+            C[torch.arange(n0), torch.randperm(n0, generator=g)] = 0.05
+        a = (torch.rand(n0, generator=g) + 0.1).double()
+        b = (torch.rand(n1, generator=g) + 0.1).double()
+        if len(probs) == 2:
+            a[5] = 0.0
+        probs.append((C.cuda(), (a / a.sum()).cuda(), (b / b.sum()).cuda()))
+    many = ops.emd_solve_many(probs, duals=True)
+    works = list(ops.emd_solve_many.last_work)
+    for k, ((C, a, b), (plan, u, v)) in enumerate(zip(probs, many)):
+        one, u1, v1 = ops.emd_solve(C, a, b, duals=True)
+        assert ops.emd_solve.last_work == works[k], k
+        assert torch.equal(plan.colptr, one.colptr) and torch.equal(plan.rowidx, one.rowidx), k
+        assert torch.equal(plan.val, one.val) and torch.equal(u, u1) and torch.equal(v, v1), k
+        _check_transport_certificate(C, a, b, plan, u, v)
+    # the C entry by itself: argument checks and what it declines
+    lib, _lib = ops.lib, ops._lib
+    n, B = 64, 2
+    z = torch.zeros(8, device='cuda', dtype=torch.float64)
+    assert lib.nif_emd_batch_workspace_bytes(n, B) > B * lib.nif_emd_workspace_bytes(n, n)
+    assert lib.nif_emd_batch_workspace_bytes(0, B) == 0
+    args = lambda **kw: [kw.get('C', z.data_ptr()), n, kw.get('stride', n * n), kw.get('n', n), B, z.data_ptr(), z.data_ptr(),
+                         kw.get('tol', z.data_ptr()), kw.get('flags', 0), z.data_ptr(), z.data_ptr(), z.data_ptr(), 200,
+                         z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), kw.get('wsz', 1 << 30), None]
+    assert lib.nif_emd_solve_batch_f32(*args(tol=None)) == -1
+    assert lib.nif_emd_solve_batch_f32(*args(stride=n * n - 1)) == -1
+    assert lib.nif_emd_solve_batch_f32(*args(flags=_lib.NIF_EMD_ARC_POOL)) == _lib.NIF_ERR_UNSUPPORTED
+    assert lib.nif_emd_solve_batch_f32(*args(wsz=1024)) == _lib.NIF_ERR_WORKSPACE
+
+
 @pytest.mark.parametrize('n0,n1,reg', [(17, 17, 0.1), (64, 48, 0.05), (150, 190, 0.06), (192, 192, 0.05), (384, 384, 0.05),
                                         (300, 771, 0.08), (1024, 1024, 0.02)])   # up to 192 x 192: the one-workgroup kernel
 def test_sinkhorn_matches_the_f64_restatement(ops, n0, n1, reg):
