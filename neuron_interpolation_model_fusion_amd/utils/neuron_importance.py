@@ -43,22 +43,42 @@ def _target_sum(logits, target):
     return logits.gather(1, target.reshape(-1, 1).to(logits.device)).sum()
 
 
-def layer_conductance(model, layer, X, y, n_steps=10):
-    """[B, *layer_output_shape] conductance of every layer unit for the target logit."""
+def _capture_all(layers):
+    boxes, handles = [], []
+    for layer in layers:
+        box, handle = _capture(layer)
+        boxes.append(box)
+        handles.append(handle)
+    return boxes, handles
+
+
+def layers_conductance(model, layers, X, y, n_steps=10):
+    """layer_conductance of several layers from ONE forward and ONE backward pass: the gradient of the target logit
+    with respect to a layer's output is the same tensor whichever other outputs the backward pass is asked for, so
+    the list equals [layer_conductance(model, l, X, y) for l in layers] (the reference runs one pass per layer)."""
     nodes = np.polynomial.legendre.leggauss(n_steps + 1)[0]
     alphas = [float(0.5 * (1.0 + t)) for t in nodes]
     B = X.shape[0]
     scaled = torch.cat([a * X for a in alphas], dim=0).requires_grad_()
-    box, handle = _capture(layer)
+    boxes, handles = _capture_all(layers)
     try:
         with torch.enable_grad():
             logits = model(scaled)
-            grads, = torch.autograd.grad(_target_sum(logits, y.repeat(n_steps + 1)), box['out'])
+            grads = torch.autograd.grad(_target_sum(logits, y.repeat(n_steps + 1)), [box['out'] for box in boxes])
     finally:
-        handle.remove()
-    evals = box['out'].detach()
-    step = (evals[B:] - evals[:-B]) * grads[:-B]
-    return step.reshape(n_steps, B, *evals.shape[1:]).sum(dim=0)
+        for handle in handles:
+            handle.remove()
+    out = []
+    for box, g in zip(boxes, grads):
+        evals = box['out'].detach()
+        step = (evals[B:] - evals[:-B]) * g[:-B]
+        out.append(step.reshape(n_steps, B, *evals.shape[1:]).sum(dim=0))
+    return out
+
+
+def layer_conductance(model, layer, X, y, n_steps=10):
+    """[B, *layer_output_shape] conductance of every layer unit for the target logit."""
+    return layers_conductance(model, [layer], X, y, n_steps)[0]
 
 
 class _RescaleFn(torch.autograd.Function):
@@ -109,21 +129,30 @@ class _RescaleRule:
         del self.module.forward  # the instance attribute shadowed the class method
 
 
-def layer_deeplift(model, layer, X, y):
-    """[B, *layer_output_shape] DeepLIFT (rescale) attribution of every layer unit, zero baseline."""
+def layers_deeplift(model, layers, X, y):
+    """layer_deeplift of several layers from ONE forward and ONE backward pass (see layers_conductance)."""
     rules = [_RescaleRule(m) for m in model.modules() if isinstance(m, _POINTWISE + (nn.MaxPool2d,))]
-    box, handle = _capture(layer)
+    boxes, handles = _capture_all(layers)
     try:
         with torch.enable_grad():
             both = torch.cat([X, torch.zeros_like(X)], dim=0).requires_grad_()
             logits = model(both)
-            grads, = torch.autograd.grad(_target_sum(logits, y.repeat(2)), box['out'])
+            grads = torch.autograd.grad(_target_sum(logits, y.repeat(2)), [box['out'] for box in boxes])
     finally:
-        handle.remove()
+        for handle in handles:
+            handle.remove()
         for r in rules:
             r.remove()
-    out, out_ref = box['out'].detach().chunk(2)
-    return grads.chunk(2)[0] * (out - out_ref)
+    out = []
+    for box, g in zip(boxes, grads):
+        o, o_ref = box['out'].detach().chunk(2)
+        out.append(g.chunk(2)[0] * (o - o_ref))
+    return out
+
+
+def layer_deeplift(model, layer, X, y):
+    """[B, *layer_output_shape] DeepLIFT (rescale) attribution of every layer unit, zero baseline."""
+    return layers_deeplift(model, [layer], X, y)[0]
 
 
 def layer_feature_ablation(model, layer, X, y):
@@ -158,6 +187,28 @@ _METHODS = {
     'deeplift': layer_deeplift,
     'featureablation': layer_feature_ablation,
 }
+
+
+_MULTI = {'conductance': layers_conductance, 'deeplift': layers_deeplift}
+
+
+def get_scores(method, model, layers, output_widths, X, y, batch_size=None):
+    """get_score for several layers of one model at once: conductance and DeepLIFT take every layer's attribution
+    from the same forward / backward pass per batch (a fusion asks for all layers of every model,
+    hf_kf.py:527-536: L passes per batch become one); feature ablation has no shared pass and runs layer by layer.
+    Per layer the arithmetic is get_score's: the same sums in the same order, so the same numbers."""
+    if method not in _MULTI:
+        return [get_score(method, model, layer, w, X, y, batch_size) for layer, w in zip(layers, output_widths)]
+    N = X.shape[0]
+    batch_size = batch_size or N
+    scores = [torch.zeros(w) for w in output_widths]
+    for lo in range(0, N, batch_size):
+        attrs = _MULTI[method](model, layers, X[lo:lo + batch_size], y[lo:lo + batch_size])
+        sums = [a.detach().abs().sum(0) for a in attrs]
+        for sc, a in zip(scores, [t.cpu() for t in sums]):
+            sc += a.sum(dim=tuple(range(1, a.ndim))) if a.ndim > 1 else a
+    device = next(model.parameters()).device
+    return [(sc / N).to(device) + EPSILON for sc in scores]
 
 
 def get_score(method, model, layer, output_width, X, y, batch_size=None):
