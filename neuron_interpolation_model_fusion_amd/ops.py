@@ -334,13 +334,22 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
             if bool(bad.any()):
                 raise ValueError('matrix contains invalid numeric entries')
         main = torch.cuda.current_stream(dev)
+        # fast mode: problems of one size go through ONE batched call (their single-workgroup phases side by side on as
+        # many compute units, one launch per kernel); they need no stream or buffers of their own
+        sizes = {}
+        if not scipy_order:
+            for C in costs:
+                sizes[C.shape[0]] = sizes.get(C.shape[0], 0) + 1
         P = []
         for C in costs:
             n = C.shape[0]
+            if sizes.get(n, 0) >= 2 and n <= LAP_BATCH_STACK_MAX_N:
+                P.append(dict(C=C, n=n, batched=True, path='fast'))
+                continue
             nbytes = lib.nif_lap_workspace_bytes(n)
             st = torch.cuda.Stream(dev)
             st.wait_stream(main)
-            P.append(dict(C=C, n=n, nbytes=nbytes, stream=st,
+            P.append(dict(C=C, n=n, nbytes=nbytes, stream=st, batched=False,
                           col=torch.empty(n, dtype=torch.int32, device=dev), row=torch.empty(n, dtype=torch.int32, device=dev),
                           u=torch.empty(n, dtype=torch.float64, device=dev), v=torch.empty(n, dtype=torch.float64, device=dev),
                           ws=torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev), path='fast'))
@@ -353,23 +362,20 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
 
         def join():
             for p in P:
-                main.wait_stream(p['stream'])
+                if not p['batched']:
+                    main.wait_stream(p['stream'])
 
         if not scipy_order:
-            # problems of one size go through ONE batched call (their single-workgroup phases side by side on as many
-            # compute units, one launch per kernel); the rest on their own streams (a process has 4 hardware queues, so
-            # streams alone overlap four problems at most)
             groups = {}
             for p in P:
-                groups.setdefault(p['n'], []).append(p)
-            for n_, ps in groups.items():
-                if len(ps) >= 2 and n_ <= LAP_BATCH_STACK_MAX_N:
-                    col, row, u, v = lap_solve_batch(torch.stack([p['C'] for p in ps]), duals=True)
-                    for b, p in enumerate(ps):
-                        p['col'], p['row'], p['u'], p['v'] = col[b], row[b], u[b], v[b]
+                if p['batched']:
+                    groups.setdefault(p['n'], []).append(p)
                 else:
-                    for p in ps:
-                        run(p, 0)
+                    run(p, 0)  # on its own stream (a process has 4 hardware queues: streams overlap four problems at most)
+            for ps in groups.values():
+                col, row, u, v = lap_solve_batch(torch.stack([p['C'] for p in ps]), duals=True)
+                for b, p in enumerate(ps):
+                    p['col'], p['row'], p['u'], p['v'] = col[b], row[b], u[b], v[b]
         else:
             for p in P:
                 p['staged'] = scipy_order is True and p['n'] >= 32
@@ -423,6 +429,8 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                             run(p, _lib.NIF_LAP_SCIPY_ORDER)
         join()
         for p in P:  # the per-problem buffers were used on side streams
+            if p['batched']:
+                continue
             for t in (p['col'], p['row'], p['u'], p['v'], p['ws'], p.get('cws'), p.get('cnt'), p.get('dup')):
                 if t is not None:
                     t.record_stream(p['stream'])
