@@ -27,10 +27,16 @@ int main() {
   EXPECT(nif_lap_workspace_bytes(8192) > 0);
   EXPECT(nif_lap_workspace_bytes(100000) == 0);
   EXPECT(nif_lap_workspace_bytes(-3) == 0);
+  EXPECT(nif_lap_batch_workspace_bytes(384, 16) == 16 * nif_lap_workspace_bytes(384));
+  EXPECT(nif_lap_batch_workspace_bytes(384, 0) == 0);
+  EXPECT(nif_lap_batch_workspace_bytes(100000, 2) == 0);
   EXPECT(nif_kmeans_workspace_bytes(24576, 3072) > (size_t)24576 * 3072 * 4);
   EXPECT(nif_kmeans_workspace_bytes(0, 5) == 0);
   EXPECT(nif_emd_workspace_bytes(2100, 1500) > 0);
   EXPECT(nif_emd_workspace_bytes(-1, 4) == 0);
+  EXPECT(nif_emd_batch_workspace_bytes(384, 4) > 4 * nif_emd_workspace_bytes(384, 384));
+  EXPECT(nif_emd_batch_workspace_bytes(384, 0) == 0);
+  EXPECT(nif_emd_batch_workspace_bytes(-1, 4) == 0);
   EXPECT(nif_eigh_kept_workspace_bytes(4609) > 0);
   EXPECT(nif_eigh_kept_workspace_bytes(NIF_EIGH_MAX_N + 1) == 0);
   EXPECT(nif_lsq_solve_workspace_bytes(4609, 1024) > 0);
@@ -44,6 +50,25 @@ int main() {
   int64_t i64 = 0;
   EXPECT(nif_xty(NULL, 4, NULL, 4, 8, 4, 4, 0, 0, 0, NULL, 4, NULL, NULL, NULL, 0, NULL) == NIF_ERR_INVALID_ARG);
   EXPECT(nif_lap_solve_f32(NULL, 4, 4, 0, NULL, NULL, NULL, NULL, NULL, 0, NULL) == NIF_ERR_INVALID_ARG);
+  {
+    // the batched entry points: every output is required, problems may not overlap, the batch must be positive
+    float c4[64];
+    int32_t i4[16];
+    double d4[16];
+    EXPECT(nif_lap_solve_batch_f32(NULL, 4, 16, 4, 2, 0, i4, i4, d4, d4, d4, 1 << 20, NULL) == NIF_ERR_INVALID_ARG);
+    EXPECT(nif_lap_solve_batch_f32(c4, 4, 16, 4, 2, 0, i4, NULL, d4, d4, d4, 1 << 20, NULL) == NIF_ERR_INVALID_ARG);
+    EXPECT(nif_lap_solve_batch_f32(c4, 4, 15, 4, 2, 0, i4, i4, d4, d4, d4, 1 << 20, NULL) == NIF_ERR_INVALID_ARG);
+    EXPECT(nif_lap_solve_batch_f32(c4, 4, 16, 4, 0, 0, i4, i4, d4, d4, d4, 1 << 20, NULL) == NIF_ERR_INVALID_ARG);
+    EXPECT(nif_lap_solve_batch_f32(c4, 4, 16, 4, 2, 0, i4, i4, d4, d4, d4, 8, NULL) == NIF_ERR_WORKSPACE);
+    EXPECT(nif_emd_solve_batch_f32(c4, 4, 16, 4, 2, d4, d4, NULL, 0, i4, i4, d4, 16, i4, d4, d4, d4, 1 << 20, NULL) ==
+           NIF_ERR_INVALID_ARG);
+    EXPECT(nif_emd_solve_batch_f32(c4, 4, 15, 4, 2, d4, d4, d4, 0, i4, i4, d4, 16, i4, d4, d4, d4, 1 << 20, NULL) ==
+           NIF_ERR_INVALID_ARG);
+    EXPECT(nif_emd_solve_batch_f32(c4, 4, 16, 4, 2, d4, d4, d4, NIF_EMD_ARC_POOL, i4, i4, d4, 16, i4, d4, d4, d4, 1 << 20,
+                                   NULL) == NIF_ERR_UNSUPPORTED);
+    EXPECT(nif_emd_solve_batch_f32(c4, 4, 16, 4, 2, d4, d4, d4, 0, i4, i4, d4, 16, i4, d4, d4, d4, 8, NULL) ==
+           NIF_ERR_WORKSPACE);
+  }
   EXPECT(nif_kmeans_lloyd_step(NULL, 4, NULL, NULL, NULL, 4, 2, NULL, NULL, NULL, NULL, NULL, 0, NULL) ==
          NIF_ERR_INVALID_ARG);
   EXPECT(nif_kmeans_lloyd_step_gf32(NULL, 4, NULL, NULL, NULL, NULL, 4, 2, NULL, NULL, NULL, NULL, NULL, 0, NULL) ==
