@@ -280,12 +280,14 @@ def lap_solve(C, duals=False, scipy_order=False):
 LAP_BATCH_STACK_MAX_N = 2048  # lap_solve_many stacks same-size cost matrices (a copy) up to this size
 
 
-def lap_solve_batch(C, duals=False, flags=0):
+def lap_solve_batch(C, duals=False, flags=0, stream=None):
     """The fast assignment solver (``lap_solve(C)``) on a stack of independent problems of one size, C [B, n, n] f32
     (row stride and problem stride taken from the tensor): ONE launch per kernel for the whole stack, the
     single-workgroup phases of the B problems side by side on B compute units (nif_lap_solve_batch_f32).  Returns
     col4row [B, n] int32 -- row b is bit-identical to ``lap_solve(C[b])`` -- and with duals=True (col4row, row4col, u, v).
-    ``flags``: NIF_LAP_* of nif_lap_solve_f32, the same for every problem (0 = the fast path)."""
+    ``flags``: NIF_LAP_* of nif_lap_solve_f32, the same for every problem (0 = the fast path).  ``stream``: a
+    torch.cuda.Stream to launch on instead of the current one (inputs and outputs are allocated on the current stream; the
+    caller orders the two streams)."""
     _need_gpu(C)
     if C.dtype != torch.float32 or C.dim() != 3 or C.shape[1] != C.shape[2]:
         raise TypeError('lap_solve_batch needs a [B, n, n] float32 tensor')
@@ -305,7 +307,9 @@ def lap_solve_batch(C, duals=False, flags=0):
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=C.device)
         lap_solve_batch.last_workspace = ws
         check(lib.nif_lap_solve_batch_f32(_ptr(C), C.stride(1), C.stride(0), n, B, flags, _ptr(col), _ptr(row), _ptr(u),
-                                          _ptr(v), _ptr(ws), nbytes, _stream()), 'nif_lap_solve_batch_f32')
+                                          _ptr(v), _ptr(ws), nbytes,
+                                          _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)),
+              'nif_lap_solve_batch_f32')
     if duals:
         return col, row, u, v
     return col
@@ -372,10 +376,17 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                     groups.setdefault(p['n'], []).append(p)
                 else:
                     run(p, 0)  # on its own stream (a process has 4 hardware queues: streams overlap four problems at most)
-            for ps in groups.values():
-                col, row, u, v = lap_solve_batch(torch.stack([p['C'] for p in ps]), duals=True)
+            side = []
+            for ps in groups.values():  # one batched call per size, the sizes side by side on streams of their own
+                stacked = torch.stack([p['C'] for p in ps])
+                st = torch.cuda.Stream(dev)
+                st.wait_stream(main)
+                col, row, u, v = lap_solve_batch(stacked, duals=True, stream=st)
+                side.append((st, stacked, lap_solve_batch.last_workspace))
                 for b, p in enumerate(ps):
                     p['col'], p['row'], p['u'], p['v'] = col[b], row[b], u[b], v[b]
+            for st, *_ in side:
+                main.wait_stream(st)
         else:
             for p in P:
                 p['staged'] = scipy_order is True and p['n'] >= 32
@@ -1047,10 +1058,11 @@ def emd_solve(C, a, b, duals=False, flags=0):
 EMD_BATCH_MAX_N = 2048  # square problems up to this size can share one batched call (the forest kernel's range)
 
 
-def _emd_launch_batch(group):
-    """One nif_emd_solve_batch_f32 call for square problems of one size: inputs stacked, every problem's output tensors
-    replaced by its rows of the stacked outputs.  False when the library declines (sizes / flags outside the batched
-    path): the caller then solves the group problem by problem."""
+def _emd_launch_batch(group, stream):
+    """One nif_emd_solve_batch_f32 call (on `stream`; everything is allocated on the current stream, which `stream` has
+    to wait for and which waits for `stream` before the results are read) for square problems of one size: inputs
+    stacked, every problem's output tensors replaced by its rows of the stacked outputs.  False when the library
+    declines (sizes / flags outside the batched path): the caller then solves the group problem by problem."""
     n, B, dev = group[0]['n0'], len(group), group[0]['dev']
     cap = group[0]['cap']
     C = torch.stack([p['C'] for p in group])
@@ -1065,11 +1077,14 @@ def _emd_launch_batch(group):
     v = torch.empty((B, n), dtype=torch.float64, device=dev)
     wsz = lib.nif_emd_batch_workspace_bytes(n, B)
     ws = torch.empty(max(wsz, 1), dtype=torch.uint8, device=dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))
     rc = lib.nif_emd_solve_batch_f32(_ptr(C), n, n * n, n, B, _ptr(a), _ptr(b), _ptr(tol), 0, _ptr(colptr), _ptr(rowidx),
-                                     _ptr(val), cap, _ptr(status), _ptr(u), _ptr(v), _ptr(ws), wsz, _stream())
+                                     _ptr(val), cap, _ptr(status), _ptr(u), _ptr(v), _ptr(ws), wsz,
+                                     ctypes.c_void_p(stream.cuda_stream))
     if rc == _lib.NIF_ERR_UNSUPPORTED:
         return False
     check(rc, 'nif_emd_solve_batch_f32')
+    group[0]['batch_keep'] = (C, a, b, tol, ws)  # alive until the caller has joined the stream
     for i, p in enumerate(group):
         p['colptr'], p['rowidx'], p['val'], p['status'], p['u'], p['v'] = colptr[i], rowidx[i], val[i], status[i], u[i], v[i]
     return True
@@ -1092,9 +1107,14 @@ def emd_solve_many(problems, duals=False):
                 groups.setdefault(p['n0'], []).append(p)
             else:
                 rest.append(p)
-        for n_, group in groups.items():
-            if len(group) < 2 or not _emd_launch_batch(group):
-                rest.extend(group)
+        side = []
+        for n_, group in groups.items():  # one batched call per size, the sizes side by side on streams of their own
+            if len(group) >= 2:
+                st = torch.cuda.Stream(dev)
+                if _emd_launch_batch(group, st):
+                    side.append(st)
+                    continue
+            rest.extend(group)
         if rest:
             tols = torch.stack([p['tol'] for p in rest]).tolist()  # one read-back for every tolerance
             streams = [torch.cuda.Stream(dev) for _ in rest]
@@ -1105,6 +1125,8 @@ def emd_solve_many(problems, duals=False):
                     _emd_launch(p, 0, st.cuda_stream)
             for st in streams:
                 main.wait_stream(st)
+        for st in side:
+            main.wait_stream(st)
         works = torch.stack([p['status'] for p in ps]).tolist()
         for i, (p, work) in enumerate(zip(ps, works)):
             if work[0] == _lib.NIF_ERR_WORKSPACE:  # outgrew the LDS arc pool: once more with the pool in global memory
