@@ -52,6 +52,14 @@ def _capture_all(layers):
     return boxes, handles
 
 
+def _grads_of_outputs(target, boxes):
+    """d target / d (captured output) of every hooked layer from one backward pass.  With several layers in one pass a
+    layer the target does not depend on gets zeros (asked for alone, autograd refuses it, as it would in the reference)."""
+    outs = [box['out'] for box in boxes]
+    grads = torch.autograd.grad(target, outs, allow_unused=len(outs) > 1)
+    return [torch.zeros_like(o) if g is None else g for o, g in zip(outs, grads)]
+
+
 def layers_conductance(model, layers, X, y, n_steps=10):
     """layer_conductance of several layers from ONE forward and ONE backward pass: the gradient of the target logit
     with respect to a layer's output is the same tensor whichever other outputs the backward pass is asked for, so
@@ -64,7 +72,7 @@ def layers_conductance(model, layers, X, y, n_steps=10):
     try:
         with torch.enable_grad():
             logits = model(scaled)
-            grads = torch.autograd.grad(_target_sum(logits, y.repeat(n_steps + 1)), [box['out'] for box in boxes])
+            grads = _grads_of_outputs(_target_sum(logits, y.repeat(n_steps + 1)), boxes)
     finally:
         for handle in handles:
             handle.remove()
@@ -137,7 +145,7 @@ def layers_deeplift(model, layers, X, y):
         with torch.enable_grad():
             both = torch.cat([X, torch.zeros_like(X)], dim=0).requires_grad_()
             logits = model(both)
-            grads = torch.autograd.grad(_target_sum(logits, y.repeat(2)), [box['out'] for box in boxes])
+            grads = _grads_of_outputs(_target_sum(logits, y.repeat(2)), boxes)
     finally:
         for handle in handles:
             handle.remove()
