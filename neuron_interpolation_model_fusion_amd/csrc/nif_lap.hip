@@ -425,8 +425,11 @@ __global__ __launch_bounds__(1024) void lap_arr_kernel(const float* __restrict__
   row4col_g += blockIdx.z * bt.vec;
   stats += blockIdx.z * bt.ws;
   extern __shared__ __attribute__((aligned(16))) int lap_sm[];
+  // v is padded to one slot per (lane, column group) when rows are register-resident: the lane's prices are then read
+  // at constant offsets from ONE per-lane address (a clamped index per column costs an address register per column)
+  const int nv = CPT > 0 ? 64 * CPT : n;
   double* v = reinterpret_cast<double*>(lap_sm);
-  int* row4col = reinterpret_cast<int*>(v + n);
+  int* row4col = reinterpret_cast<int*>(v + nv);
   int* queue = row4col + n;
   double* bid_gamma = reinterpret_cast<double*>(queue + n + (n & 1));
   int* bid_col = reinterpret_cast<int*>(bid_gamma + ARR_W);
@@ -464,18 +467,22 @@ __global__ __launch_bounds__(1024) void lap_arr_kernel(const float* __restrict__
     v[j] = vg[j];
     row4col[j] = row4col_g[j];
   }
+  for (int j = n + tid; j < nv; j += T) v[j] = 0.0;
   const int total = compact_free();  // ends with a barrier: v / row4col / queue are visible
 
   float bufA[R], bufB[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) bufA[q] = bufB[q] = 0.f;
-  auto request_row = [&](int row, float* buf) __attribute__((always_inline)) {  // clamped addresses: every load in flight, nothing to wait behind
-    const float* __restrict__ crow = C + (int64_t)row * ldc;
+  // The cost matrix as a buffer resource: a row's columns are loaded at constant offsets from one per-lane offset plus
+  // the row's scalar offset -- every load in flight, no guards, no per-column address registers.  Slots past column n
+  // read into the next row (discarded by the bid scan) or, past the end of the matrix, the range check's zero.
+  const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(C), 0, (int)((((unsigned)(n - 1)) * (unsigned)ldc + (unsigned)n) * 4u), 0x00020000);
+  auto request_row = [&](int row, float* buf) __attribute__((always_inline)) {
+    const unsigned rowoff = (unsigned)row * (unsigned)ldc * 4u;  // row is wave-uniform: a scalar
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int j = lane + 64 * q;
-      buf[q] = crow[j < n ? j : n - 1];
-    }
+    for (int q = 0; q < R; ++q)
+      buf[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, lane * 4 + 256 * q, rowoff, 0));
   };
 
   int cur = -1;    // the row this wave bids for
@@ -531,14 +538,17 @@ __global__ __launch_bounds__(1024) void lap_arr_kernel(const float* __restrict__
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         NIF_ARR_MARK(1);
 #endif
-        double vj[R];
+        // the prices of the lane's columns eight at a time: all R at once would put 2 R more registers beside the two row
+        // sets (R = 16 spilled that way, and wider rows had to be re-read from L2 every pass)
+        constexpr int VC = R < 8 ? R : 8;
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-          const int j = lane + 64 * q;
-          vj[q] = v[j < n ? j : n - 1];
+        for (int q0 = 0; q0 < R; q0 += VC) {
+          double vj[VC];
+#pragma unroll
+          for (int q = 0; q < VC; ++q) vj[q] = v[lane + 64 * (q0 + q)];  // (padded: no clamp)
+#pragma unroll
+          for (int q = 0; q < VC; ++q) take(bufA[q0 + q], vj[q], lane + 64 * (q0 + q));
         }
-#pragma unroll
-        for (int q = 0; q < R; ++q) take(bufA[q], vj[q], lane + 64 * q);
       } else {
         const float* __restrict__ crow = C + (int64_t)cur * ldc;
         for (int t0 = 0; t0 < n; t0 += 512) {
@@ -988,23 +998,28 @@ static int lap_solve_on(const float* C, int64_t ldc, int n, int flags, int32_t* 
     const int arr_min_chains = getenv("NIF_LAP_ARR_MIN_CHAINS") ? env_int("NIF_LAP_ARR_MIN_CHAINS") : 6;
     const int arr_max_wait = getenv("NIF_LAP_ARR_MAX_WAIT") ? env_int("NIF_LAP_ARR_MAX_WAIT") : 4;
     if (arr_passes > 0) {
-      const size_t arr_lds = (size_t)n * 16 + (n & 1) * 4 + ARR_W * 16 + 32 * sizeof(int);
+      // LDS: v (padded to 64 CPT slots when rows are register-resident) + row4col + queue + bids / flags
 #define NIF_ARR_GO(CPT)                                                                                               \
   do {                                                                                                                \
+    const size_t nv = CPT > 0 ? (size_t)64 * CPT : (size_t)n;                                                         \
+    const size_t arr_lds = nv * 8 + (size_t)n * 8 + (n & 1) * 4 + ARR_W * 16 + 32 * sizeof(int);                      \
     auto kfn = lap_arr_kernel<CPT>;                                                                                   \
     if (arr_lds > 48 * 1024)                                                                                          \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)arr_lds);          \
     hipLaunchKernelGGL(kfn, dim3(1, 1, bz), dim3(1024), arr_lds, st, C, ldc, n, uu, vv, col4row, r4c, jbest, arr_passes, \
                        arr_min_chains, arr_max_wait, bt);                                                           \
   } while (0)
-      const int cols = (n + 63) / 64;  // columns a lane holds of its bidder's row
+      int cols = (n + 63) / 64;  // columns a lane holds of its bidder's row
+      // (the register-resident kernels address the matrix through a 32-bit buffer offset)
+      if (((uint64_t)(n - 1) * (uint64_t)ldc + (uint64_t)n) * 4 >= 0xffffffffull) cols = 1 << 20;
       if (cols <= 2) NIF_ARR_GO(2);
       else if (cols <= 4) NIF_ARR_GO(4);
       else if (cols <= 6) NIF_ARR_GO(6);
       else if (cols <= 8) NIF_ARR_GO(8);
       else if (cols <= 12) NIF_ARR_GO(12);
       else if (cols <= 16) NIF_ARR_GO(16);
-      else NIF_ARR_GO(0);  // two register sets of more than 16 columns spill: these sizes re-read the row from L2
+      else NIF_ARR_GO(0);  // two register sets of more than 16 columns spill (24: 340 B, 32: 4.6 KB of scratch a lane with
+                           // sixteen waves on the CU): these sizes re-read the row from L2
 #undef NIF_ARR_GO
     }
   }
