@@ -1219,7 +1219,7 @@ def test_lap_solve_many_equals_one_by_one(ops):
             assert (linear_sum_assignment(C.cpu().numpy())[1] == col.cpu().numpy()).all()
 
 
-@pytest.mark.parametrize('n,B', [(1, 3), (37, 5), (130, 4), (384, 9), (1100, 3), (2100, 2)])
+@pytest.mark.parametrize('n,B', [(1, 3), (37, 5), (64, 1), (130, 4), (384, 9), (900, 2), (1100, 3), (2100, 2)])
 def test_lap_solve_batch_equals_one_call_per_problem(ops, n, B):
     """nif_lap_solve_batch_f32 (the problems along gridDim.z of every kernel): matchings AND duals bit-identical to one
     nif_lap_solve_f32 call per problem -- hard instances (unrelated activations), a planted one, a tie-laden one; row and
@@ -1238,7 +1238,6 @@ def test_lap_solve_batch_equals_one_call_per_problem(ops, n, B):
         big[b, :n, :n] = probs[b]
     big = big.cuda()
     C = big[:, :n, :n]                                               # strides (n + 3) (n + 5), n + 5, 1
-    assert not C.is_contiguous() or n == 0
     for flags in (0, ops._lib.NIF_LAP_SCIPY_ORDER):
         col, row, u, v = ops.lap_solve_batch(C, duals=True, flags=flags)
         for b in range(B):
