@@ -364,10 +364,34 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                                             _ptr(p['u']), _ptr(p['v']), _ptr(p['ws']), p['nbytes'],
                                             ctypes.c_void_p(p['stream'].cuda_stream)), 'nif_lap_solve_f32')
 
+        side = []  # (stream, tensors kept alive) of the batched calls
+
         def join():
             for p in P:
                 if not p['batched']:
                     main.wait_stream(p['stream'])
+            for st, *_ in side:
+                main.wait_stream(st)
+
+        def replay_all(ps):
+            """The kernel that replays scipy's order for `ps` (main has joined their streams): problems of one size as ONE
+            batched call on a stream of its own -- their single-workgroup searches side by side however many they are --
+            the rest on their own streams (four hardware queues: four at a time)."""
+            by_size = {}
+            for p in ps:
+                by_size.setdefault(p['n'], []).append(p)
+            for n_, g in by_size.items():
+                if len(g) >= 2 and n_ <= LAP_BATCH_STACK_MAX_N:
+                    stacked = torch.stack([p['C'] for p in g])
+                    st = torch.cuda.Stream(dev)
+                    st.wait_stream(main)
+                    col, row, u, v = lap_solve_batch(stacked, duals=True, flags=_lib.NIF_LAP_SCIPY_ORDER, stream=st)
+                    side.append((st, stacked, lap_solve_batch.last_workspace))
+                    for b, p in enumerate(g):
+                        p['col'], p['row'], p['u'], p['v'] = col[b], row[b], u[b], v[b]
+                else:
+                    for p in g:
+                        run(p, _lib.NIF_LAP_SCIPY_ORDER)
 
         if not scipy_order:
             groups = {}
@@ -376,7 +400,6 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                     groups.setdefault(p['n'], []).append(p)
                 else:
                     run(p, 0)  # on its own stream (a process has 4 hardware queues: streams overlap four problems at most)
-            side = []
             for ps in groups.values():  # one batched call per size, the sizes side by side on streams of their own
                 stacked = torch.stack([p['C'] for p in ps])
                 st = torch.cuda.Stream(dev)
@@ -385,19 +408,20 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                 side.append((st, stacked, lap_solve_batch.last_workspace))
                 for b, p in enumerate(ps):
                     p['col'], p['row'], p['u'], p['v'] = col[b], row[b], u[b], v[b]
-            for st, *_ in side:
-                main.wait_stream(st)
         else:
             for p in P:
                 p['staged'] = scipy_order is True and p['n'] >= 32
             staged = [p for p in P if p['staged']]
+            replays = []
             for p in P:
                 p['path'] = 'replay'
                 if p['staged']:
                     run(p, _lib.NIF_LAP_INIT_ONLY)
                 else:
-                    run(p, _lib.NIF_LAP_SCIPY_ORDER)
-            if staged:
+                    replays.append(p)
+            if not staged:
+                replay_all(replays)
+            else:
                 join()
                 free = torch.stack([(p['col'] < 0).sum() for p in staged]).tolist()   # one read-back for all
                 # the duplicate-line filter only for the problems the initialisation did not nearly solve (one more
@@ -430,14 +454,17 @@ def lap_solve_many(costs, scipy_order=True, rows=False):
                                   'nif_lap_certify_unique_f32')
                         certs.append(p)
                     else:
-                        run(p, _lib.NIF_LAP_SCIPY_ORDER)
+                        replays.append(p)
+                replay_all(replays)
                 if certs:
                     join()
+                    failed = []
                     for p, c in zip(certs, torch.cat([p['cnt'] for p in certs]).tolist()):
                         if c == 0:
                             p['path'] = 'certified'
                         else:
-                            run(p, _lib.NIF_LAP_SCIPY_ORDER)
+                            failed.append(p)
+                    replay_all(failed)
         join()
         for p in P:  # the per-problem buffers were used on side streams
             if p['batched']:

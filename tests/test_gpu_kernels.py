@@ -1284,3 +1284,22 @@ def test_lap_solve_many_batches_same_size_problems(ops):
     for a, b, r in zip(one, many, rows):
         assert torch.equal(a, b)
         assert torch.equal(r[b.long()].long(), torch.arange(b.shape[0], device='cuda'))
+    # scipy order: the replays of same-size problems (tie-laden costs, and sizes below the staged path's 32) are one
+    # batched call per size; certified problems stay on their own streams.  Same matchings and paths as one by one, = scipy
+    from scipy.optimize import linear_sum_assignment
+    tied = []
+    for k in range(3):
+        t = torch.rand(96, 96, generator=g)
+        t[:, 48:] = t[:, :48]                       # duplicated columns: exact ties -> replay
+        tied.append(t.cuda())
+    small = [torch.randint(0, 3, (16, 16), generator=g).float().cuda() for _ in range(3)]   # n < 32: replay at once
+    mixed = [tied[0], costs[0], small[0], tied[1], costs[2], small[1], tied[2], small[2], costs[1]]
+    paths = []
+    for C in mixed:
+        ops.lap_solve(C, scipy_order=True)
+        paths.append(ops.lap_solve.last_path)
+    many, rows = ops.lap_solve_many(mixed, scipy_order=True, rows=True)
+    assert ops.lap_solve_many.last_paths == paths and paths.count('replay') >= 6
+    for C, col, r in zip(mixed, many, rows):
+        assert (linear_sum_assignment(C.cpu().numpy())[1] == col.cpu().numpy()).all()
+        assert torch.equal(r[col.long()].long(), torch.arange(col.shape[0], device='cuda'))
